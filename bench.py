@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- trajectory rollouts/s of the MPPI hot path on MI355X (BASELINE.json metric).
+
+A "step" is one whole MPPI iteration (sample + rollout + cost + weights + update) over one batch of K samples
+of synthetic input; the workload at N=1 is BASELINE.json configs[1] (C2: diff_drive, K=65 536, T=50, sinusoid
+reference path, launch parameters).  With N>1 ranks (one process per GPU, torch.distributed/RCCL) K is sharded:
+every rank rolls out K=65 536 samples with global sample ids (weak scaling; N=8 is BASELINE configs[4], K=524 288)
+and the per-rank partials [sum w, sum w*u] are all-reduced once per iteration.
+
+Inputs (pose + reference window) are precomputed on the host and passed as kernel arguments; the warm start u*
+stays resident in HBM and evolves from step to step.  Nothing under oracle/ is touched except for the
+`cpu_baseline` leg (rank 0, N=1), which times the CPU restatement of the reference loop on the host.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def algorithmic_bytes(T, udim):
+    """B = 8*[2*(T-1)*u_dim + 2*T + 2] per rollout for the whole iteration; the rollout kernel's
+    share is controls written once + x,y written once + weight written once."""
+    whole = 8 * (2 * (T - 1) * udim + 2 * T + 2)
+    rollout_kernel = 8 * ((T - 1) * udim + 2 * T + 1)
+    return whole, rollout_kernel
+
+
+def script_inputs(amd, w, n):
+    """n (pose, window) pairs along the reference path: the robot advances ~v_ref*dt per step with a small lateral
+    and heading offset, as a tracking controller would see them."""
+    p = w.params
+    px, py = amd.make_path(w.path)
+    rng = np.random.default_rng(0)
+    span = max(1, len(px) - 2 * p.horizon // 3)
+    out = []
+    for i in range(n):
+        j = int(i * p.v_ref * p.dt / p.resolution) % span
+        yaw = np.arctan2(py[j + 1] - py[j], px[j + 1] - px[j])
+        s = np.zeros(p.nstate)
+        s[0], s[1], s[2] = px[j] + rng.normal(0, 0.03), py[j] + rng.normal(0, 0.03), yaw + rng.normal(0, 0.05)
+        _, xr, yr, yawr = amd.calc_ref_path(px, py, s[0], s[1], p.v_ref, p.dt, p.resolution, p.horizon)
+        out.append((s, xr, yr, float(yawr[0])))
+    return out
+
+
+def cpu_baseline(w, budget_s=12.0):
+    """The oracle (CPU restatement of the reference's single-threaded loop, mt19937 mode) on a bounded sample of the
+    same workload: whole iterations of the full K until ~budget_s of CPU time is spent."""
+    import ccv_mppi_path_tracker_amd as amd
+    from oracle import oracle_lib as O
+    p = w.params
+    o = O.Oracle(p.model, p.num_samples, p.horizon, p.control_noise, p.lam, p.v_ref, p.u_min, p.u_max,
+                 path_weight=p.path_weight, v_weight=p.v_weight, zmp_weight=p.zmp_weight, roll_v_weight=p.roll_v_weight,
+                 back_weight=p.back_weight, yaw_weight=p.yaw_weight, roll_off=p.roll_off, steer_off=p.steer_off)
+    inputs = script_inputs(amd, w, 16)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        s, xr, yr, yaw0 = inputs[n % len(inputs)]
+        o.iterate(s, p.dt, xr, yr, yaw0, seed=42 + n, rng="mt19937")
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {"value": p.num_samples * n / el, "unit": "rollouts/s", "cores": 1, "kind": "port",
+            "sample": "%d whole iterations of %s (oracle/mppi_oracle.cpp, serial mt19937 like the reference, "
+                      "%.1f s, %.0f ms/iteration)" % (n, w.description, el, 1e3 * el / n),
+            "host_cpus": os.cpu_count()}
+
+
+def latest_pmc_traffic(workload_name):
+    """HBM bytes per rollout-kernel launch from the committed rocprofv3 --pmc summary (profiles/*pmc*.json)."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("workload") == workload_name and d.get("hbm_bytes_per_launch"):
+                best = float(d["hbm_bytes_per_launch"])
+        except Exception:
+            pass
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C2", help="C2 (headline) | C3 | C4")
+    ap.add_argument("--samples-per-gpu", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-state-store", action="store_true", help="skip the KxH x,y buffer (not the headline)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ccv_mppi_path_tracker_amd as amd
+    from ccv_mppi_path_tracker_amd import configs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w = configs.workload(args.workload)
+    p = w.params
+    k_local = args.samples_per_gpu or p.num_samples
+    k_total = k_local * world
+    ctl = amd.MPPIController(p, device=local_rank, num_samples=k_local, sample_offset=rank * k_local,
+                             no_state_store=args.no_state_store)
+    stream = torch.cuda.current_stream()
+    ctl.set_stream(stream.cuda_stream)
+    inputs = script_inputs(amd, w, 64)
+    partials = torch.zeros(ctl.partials_size(), dtype=torch.float64, device="cuda")
+    pptr = partials.data_ptr()
+    seed = 42
+
+    def step(i):
+        s, xr, yr, yaw0 = inputs[i % len(inputs)]
+        if world == 1:
+            ctl.iterate_enqueue(s, p.dt, xr, yr, yaw0, seed, i)
+        else:
+            # per-GPU partials [sum w, sum w*u] -> one small RCCL all-reduce over xGMI -> every rank divides
+            ctl.iterate_partials_enqueue(s, p.dt, xr, yr, yaw0, seed, i, pptr)
+            dist.all_reduce(partials)
+            ctl.apply_partials_enqueue(pptr)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ctl.timing_enable(True)        # hipEvents around the rollout kernel and the whole launch sequence, on `stream`
+    ctl.timing_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    roll_us, iter_us, n_ev = ctl.timing_read(reset=True)
+    ctl.timing_enable(False)
+    u_final = ctl.get_nominal()
+    if not np.all(np.isfinite(u_final)):
+        print("bench.py: non-finite controls after the timed region", file=sys.stderr)
+        sys.exit(4)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        B, B_roll = algorithmic_bytes(p.horizon, p.udim)
+        roll_avg_s = roll_us / max(n_ev, 1) * 1e-6
+        iter_avg_s = iter_us / max(n_ev, 1) * 1e-6
+        achieved = B_roll * k_local / roll_avg_s / 1e9 if roll_avg_s > 0 else None
+        traffic = latest_pmc_traffic(args.workload) if world == 1 else None
+        out = {
+            "metric": "trajectory rollouts/s (K x iters/s), diff-drive T=50" if args.workload == "C2"
+                      else "trajectory rollouts/s (K x iters/s)",
+            "value": k_total * args.steps / elapsed,
+            "unit": "rollouts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s, u_dim=%d, launch parameters" % (w.name, w.description.replace(
+                "K=%d" % p.num_samples, "K=%d" % k_total), p.udim),
+                       "samples_per_gpu": k_local, "horizon": p.horizon, "sharding": "K over %d GPU(s)" % world,
+                       "state_store": not args.no_state_store},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "kernel": "k_rollout_cost", "kernel_avg_us": 1e6 * roll_avg_s,
+                         "algorithmic_bytes_per_launch": B_roll * k_local,
+                         "iteration_avg_us": 1e6 * iter_avg_s,
+                         "iteration_algorithmic_bytes": B * k_local,
+                         "iteration_achieved": (B * k_local / iter_avg_s / 1e9) if iter_avg_s > 0 else None,
+                         "iteration_frac": (B * k_local / iter_avg_s / 1e9 / HBM_PEAK_GBS) if iter_avg_s > 0 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

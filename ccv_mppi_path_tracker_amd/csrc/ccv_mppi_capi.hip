@@ -1,0 +1,614 @@
+// C ABI (include/ccv_mppi.h) over the gfx950 kernels of mppi_kernels.h.
+// Host side only orchestrates: allocate once, build the window coefficients, launch, copy u* back.
+// There is deliberately no CPU fallback: every entry point fails with CCV_MPPI_ERR_NO_DEVICE / _HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mppi_kernels.h"
+
+using namespace ccv;
+
+struct ccv_mppi_handle {
+    ccv_mppi_config cfg{};
+    int udim = 0, K = 0, H = 0, R = 0, pitch = 0, nchunks = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // device buffers
+    double* d_nominal = nullptr;
+    double* d_u = nullptr;
+    double* d_xs = nullptr;
+    double* d_ys = nullptr;
+    double* d_cost = nullptr;
+    double* d_w = nullptr;
+    double* d_partial = nullptr;
+    double* d_statpart = nullptr;
+    double* d_vec = nullptr;
+    double* d_stats = nullptr;
+    double* d_cmin = nullptr;
+    double* d_scratch = nullptr;  // read-back staging
+    size_t scratch_bytes = 0;
+    // pinned host staging
+    double* h_pin = nullptr;
+    size_t pin_doubles = 0;
+    // stage-wise state
+    bool have_controls = false, have_rollout = false, have_weights = false;
+    double st_x0[5] = {0, 0, 0, 0, 0};
+    double st_dt = 0.1;
+    // window of the last cost evaluation
+    int lds_window = 1;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // triples: start, after rollout, end
+    size_t ev_used = 0;
+    double t_roll_sum = 0.0, t_iter_sum = 0.0;
+    int64_t t_n = 0;
+    float last_iter_us = 0.f, last_roll_us = 0.f;
+    std::string err;
+};
+
+namespace {
+
+const char* kVersion = "ccv_mppi_hip 0.1 (gfx950)";
+
+int fail(ccv_mppi_handle* h, int code, const char* what, hipError_t e = hipSuccess) {
+    if (h) {
+        h->err = what;
+        if (e != hipSuccess) {
+            h->err += ": ";
+            h->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                            \
+    do {                                                                            \
+        hipError_t e__ = (call);                                                    \
+        if (e__ != hipSuccess) return fail((h), CCV_MPPI_ERR_HIP, #call, e__);      \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int ensure_scratch(ccv_mppi_handle* h, size_t bytes) {
+    if (bytes <= h->scratch_bytes) return CCV_MPPI_OK;
+    if (h->d_scratch) HIP_TRY(h, hipFree(h->d_scratch));
+    h->d_scratch = nullptr;
+    h->scratch_bytes = 0;
+    HIP_TRY(h, hipMalloc(&h->d_scratch, bytes));
+    h->scratch_bytes = bytes;
+    return CCV_MPPI_OK;
+}
+
+void fill_args(const ccv_mppi_handle* h, RolloutArgs& A, const double* x0, double dt, double yaw_ref0, uint64_t seed,
+               uint64_t iter) {
+    const ccv_mppi_config& c = h->cfg;
+    std::memset(&A, 0, sizeof(A));
+    const int nx = c.model == CCV_MPPI_FULL_BODY ? 5 : 3;
+    for (int i = 0; i < nx; ++i) A.x0[i] = x0[i];
+    A.dt = dt;
+    A.yaw_ref0 = yaw_ref0;
+    A.sigma = c.control_noise;
+    A.lambda = c.lambda;
+    A.v_ref = c.v_ref;
+    for (int d = 0; d < CCV_MPPI_MAX_UDIM; ++d) {
+        A.umin[d] = c.u_min[d];
+        A.umax[d] = c.u_max[d];
+    }
+    const bool roll_off = (c.flags & CCV_MPPI_FLAG_ROLL_OFF) != 0;
+    A.w_path = c.path_weight;
+    A.w_v = c.v_weight;
+    A.w_zmp = roll_off ? 0.0 : c.zmp_weight;        // fb:43-46
+    A.w_rollv = roll_off ? 0.0 : c.roll_v_weight;
+    A.w_back = c.back_weight;
+    A.w_yaw = c.yaw_weight;
+    // fb.h:212-216, fb:86-91
+    const double upper_body_height = 0.8075, upper_body_width = 0.208, mass = 60.0;
+    const double base2CoM = upper_body_height / 2;
+    A.fb_mass = mass;
+    A.fb_L = base2CoM;
+    A.fb_Ixx = (mass * (upper_body_width * upper_body_width + upper_body_height * upper_body_height)) / 12 + mass * base2CoM * base2CoM;
+    A.fb_gz = -9.8;  // fb.h:30
+    A.seed_lo = (uint32_t)seed;
+    A.seed_hi = (uint32_t)(seed >> 32);
+    A.iter_lo = (uint32_t)iter;
+    A.iter_hi = (uint32_t)(iter >> 32);
+    A.K = h->K;
+    A.pitch = h->pitch;
+    A.H = h->H;
+    A.k_offset = c.sample_offset;
+    A.steer_off = (c.flags & CCV_MPPI_FLAG_STEER_OFF) ? 1 : 0;
+    A.nominal = h->d_nominal;
+    A.u = h->d_u;
+    A.xs = h->d_xs;
+    A.ys = h->d_ys;
+    A.cost = h->d_cost;
+    A.w = h->d_w;
+}
+
+// Window coefficients relative to the current pose: |p - r_j|^2 = |p|^2 + a_j px + b_j py + c_j
+void fill_window(const ccv_mppi_handle* h, Window& W, const double* x0, const double* x_ref, const double* y_ref) {
+    for (int j = 0; j < h->H; ++j) {
+        const double xl = x_ref[j] - x0[0], yl = y_ref[j] - x0[1];
+        W.a[j] = -2.0 * xl;
+        W.b[j] = -2.0 * yl;
+        W.c[j] = xl * xl + yl * yl;
+    }
+}
+
+template <int MODEL>
+void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int src) {
+    const dim3 grid((h->K + kBlock - 1) / kBlock), block(kBlock);
+    if (src == SRC_PHILOX) {
+        if (h->lds_window) hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_PHILOX, true>), grid, block, 0, h->stream, A, W);
+        else hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_PHILOX, false>), grid, block, 0, h->stream, A, W);
+    } else {
+        if (h->lds_window) hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_BUFFER, true>), grid, block, 0, h->stream, A, W);
+        else hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_BUFFER, false>), grid, block, 0, h->stream, A, W);
+    }
+}
+
+int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int src) {
+    switch (h->cfg.model) {
+        case CCV_MPPI_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_DIFF_DRIVE>(h, A, W, src); break;
+        case CCV_MPPI_STEERING_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_STEERING_DIFF_DRIVE>(h, A, W, src); break;
+        default: launch_rollout_model<CCV_MPPI_FULL_BODY>(h, A, W, src); break;
+    }
+    HIP_TRY(h, hipGetLastError());
+    return CCV_MPPI_OK;
+}
+
+int launch_sample(ccv_mppi_handle* h, const RolloutArgs& A) {
+    const dim3 grid((h->K + kBlock - 1) / kBlock, (h->R + 3) / 4), block(kBlock);
+    switch (h->cfg.model) {
+        case CCV_MPPI_DIFF_DRIVE: hipLaunchKernelGGL((k_sample<CCV_MPPI_DIFF_DRIVE>), grid, block, 0, h->stream, A); break;
+        case CCV_MPPI_STEERING_DIFF_DRIVE: hipLaunchKernelGGL((k_sample<CCV_MPPI_STEERING_DIFF_DRIVE>), grid, block, 0, h->stream, A); break;
+        default: hipLaunchKernelGGL((k_sample<CCV_MPPI_FULL_BODY>), grid, block, 0, h->stream, A); break;
+    }
+    HIP_TRY(h, hipGetLastError());
+    return CCV_MPPI_OK;
+}
+
+// weights -> [sum w, sum w*u] (-> u* when `normalise`); vec_out may be a caller-owned device buffer.
+int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out) {
+    if (h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT) {
+        hipLaunchKernelGGL(k_min_cost, dim3(1), dim3(1024), 0, h->stream, h->d_cost, h->K, h->d_cmin);
+        hipLaunchKernelGGL(k_reweight, dim3((h->K + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_cost, h->d_cmin,
+                           h->cfg.lambda, h->K, h->d_w);
+    }
+    UpdateArgs U;
+    U.u = h->d_u;
+    U.w = h->d_w;
+    U.cost = h->d_cost;
+    U.partial = h->d_partial;
+    U.statpart = h->d_statpart;
+    U.K = h->K;
+    U.pitch = h->pitch;
+    U.R = h->R;
+    U.nchunks = h->nchunks;
+    hipLaunchKernelGGL(k_update_partials, dim3(h->nchunks, h->R + 1), dim3(kBlock), 0, h->stream, U);
+    FinalizeArgs F;
+    F.partial = h->d_partial;
+    F.statpart = h->d_statpart;
+    F.nominal = h->d_nominal;
+    F.vec = vec_out ? vec_out : h->d_vec;
+    F.stats = h->d_stats;
+    F.R = h->R;
+    F.nchunks = h->nchunks;
+    F.normalise = normalise ? 1 : 0;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, h->stream, F);
+    HIP_TRY(h, hipGetLastError());
+    return CCV_MPPI_OK;
+}
+
+int timing_begin(ccv_mppi_handle* h, size_t& slot) {
+    slot = h->ev_used;
+    if (h->ev.size() < slot + 3) {
+        for (int i = 0; i < 3; ++i) {
+            hipEvent_t e;
+            HIP_TRY(h, hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+    }
+    h->ev_used += 3;
+    HIP_TRY(h, hipEventRecord(h->ev[slot], h->stream));
+    return CCV_MPPI_OK;
+}
+
+int timing_collect(ccv_mppi_handle* h) {
+    if (h->ev_used == 0) return CCV_MPPI_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (size_t s = 0; s + 3 <= h->ev_used; s += 3) {
+        float a = 0.f, b = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&a, h->ev[s], h->ev[s + 1]));
+        HIP_TRY(h, hipEventElapsedTime(&b, h->ev[s], h->ev[s + 2]));
+        h->t_roll_sum += (double)a * 1000.0;
+        h->t_iter_sum += (double)b * 1000.0;
+        h->t_n += 1;
+        h->last_roll_us = a * 1000.f;
+        h->last_iter_us = b * 1000.f;
+    }
+    h->ev_used = 0;
+    return CCV_MPPI_OK;
+}
+
+int check_iter_args(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref, const double* y_ref) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!x0 || !x_ref || !y_ref) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "null pointer argument");
+    if (!(dt == dt)) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "dt is NaN");
+    return CCV_MPPI_OK;
+}
+
+// the fused iteration: sample+rollout+cost kernel, then the weighted update
+int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref, const double* y_ref,
+                      double yaw_ref0, uint64_t seed, uint64_t iter, bool normalise, double* vec_out) {
+    RolloutArgs A;
+    Window W;
+    fill_args(h, A, x0, dt, yaw_ref0, seed, iter);
+    fill_window(h, W, x0, x_ref, y_ref);
+    A.store_u = 1;
+    A.store_xy = (h->cfg.flags & CCV_MPPI_FLAG_NO_STATE_STORE) ? 0 : 1;
+    A.do_cost = 1;
+    size_t slot = 0;
+    if (h->timing) {
+        int rc = timing_begin(h, slot);
+        if (rc) return rc;
+    }
+    int rc = launch_rollout(h, A, W, SRC_PHILOX);
+    if (rc) return rc;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[slot + 1], h->stream));
+    rc = launch_update(h, normalise, vec_out);
+    if (rc) return rc;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[slot + 2], h->stream));
+    std::memcpy(h->st_x0, A.x0, sizeof(h->st_x0));
+    h->st_dt = dt;
+    h->have_controls = h->have_rollout = h->have_weights = true;
+    return CCV_MPPI_OK;
+}
+
+int fetch_result(ccv_mppi_handle* h, double* u_opt_out, ccv_mppi_stats* stats) {
+    // one D2H of [u* | stats] through pinned memory, then a stream sync
+    const size_t n = (size_t)h->R;
+    HIP_TRY(h, hipMemcpyAsync(h->h_pin, h->d_nominal, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_pin + n, h->d_stats, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int nonfinite = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!std::isfinite(h->h_pin[i])) nonfinite = 1;
+        if (u_opt_out) u_opt_out[i] = h->h_pin[i];
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->sum_w = h->h_pin[n + 0];
+        stats->min_cost = h->h_pin[n + 1];
+        stats->max_cost = h->h_pin[n + 2];
+        stats->n_zero_weight = (int64_t)h->h_pin[n + 3];
+        stats->nonfinite = nonfinite;
+        if (h->timing) {
+            int rc = timing_collect(h);
+            if (rc) return rc;
+            stats->device_us = h->last_iter_us;
+            stats->rollout_us = h->last_roll_us;
+        }
+    }
+    return CCV_MPPI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ccv_mppi_version(void) { return kVersion; }
+
+int ccv_mppi_udim(int model) {
+    if (model < CCV_MPPI_DIFF_DRIVE || model > CCV_MPPI_FULL_BODY) return CCV_MPPI_ERR_INVALID_ARG;
+    return udim_of(model);
+}
+
+const char* ccv_mppi_last_error(const ccv_mppi_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
+    if (!cfg || !out) return CCV_MPPI_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->abi_version != CCV_MPPI_ABI_VERSION) return CCV_MPPI_ERR_INVALID_ARG;
+    if (cfg->model < CCV_MPPI_DIFF_DRIVE || cfg->model > CCV_MPPI_FULL_BODY) return CCV_MPPI_ERR_INVALID_ARG;
+    if (cfg->num_samples < 1 || cfg->horizon < 3 || cfg->horizon > CCV_MPPI_MAX_HORIZON) return CCV_MPPI_ERR_INVALID_ARG;
+    if (cfg->sample_offset < 0) return CCV_MPPI_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CCV_MPPI_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return CCV_MPPI_ERR_NO_DEVICE;
+    ccv_mppi_handle* h = new (std::nothrow) ccv_mppi_handle();
+    if (!h) return CCV_MPPI_ERR_ALLOC;
+    h->cfg = *cfg;
+    h->udim = udim_of(cfg->model);
+    h->K = cfg->num_samples;
+    h->H = cfg->horizon;
+    h->R = (h->H - 1) * h->udim;
+    h->pitch = round_up(h->K, 64);
+    h->nchunks = (h->K + kChunk - 1) / kChunk;
+    const char* env = getenv("CCV_MPPI_WINDOW");
+    h->lds_window = !(env && std::strcmp(env, "scalar") == 0);
+
+    auto bail = [&](int code, const char* what, hipError_t e) {
+        fail(h, code, what, e);
+        std::fprintf(stderr, "ccv_mppi_create: %s\n", h->err.c_str());
+        ccv_mppi_destroy(h);
+        return code;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail(CCV_MPPI_ERR_NO_DEVICE, "hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipStreamCreate", e);
+    h->stream = h->own_stream;
+    const size_t P = (size_t)h->pitch;
+    struct { double** p; size_t n; } allocs[] = {
+        {&h->d_nominal, (size_t)h->R},
+        {&h->d_u, (size_t)h->R * P},
+        {&h->d_xs, (size_t)h->H * P},
+        {&h->d_ys, (size_t)h->H * P},
+        {&h->d_cost, P},
+        {&h->d_w, P},
+        {&h->d_partial, (size_t)(h->R + 1) * h->nchunks},
+        {&h->d_statpart, (size_t)h->nchunks * 3},
+        {&h->d_vec, (size_t)h->R + 1},
+        {&h->d_stats, 4},
+        {&h->d_cmin, 1},
+    };
+    for (auto& a : allocs) {
+        if ((e = hipMalloc(a.p, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
+        if ((e = hipMemset(*a.p, 0, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipMemset", e);
+    }
+    h->pin_doubles = (size_t)h->R + 16;
+    if ((e = hipHostMalloc(&h->h_pin, h->pin_doubles * sizeof(double), hipHostMallocDefault)) != hipSuccess)
+        return bail(CCV_MPPI_ERR_ALLOC, "hipHostMalloc", e);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipDeviceSynchronize", e);
+    *out = h;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_destroy(ccv_mppi_handle* h) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    double* bufs[] = {h->d_nominal, h->d_u, h->d_xs, h->d_ys, h->d_cost, h->d_w, h->d_partial, h->d_statpart,
+                      h->d_vec, h->d_stats, h->d_cmin, h->d_scratch};
+    for (double* b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_set_stream(ccv_mppi_handle* h, void* hip_stream) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_synchronize(ccv_mppi_handle* h) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_set_nominal(ccv_mppi_handle* h, const double* u) {
+    if (!h || !u) return CCV_MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipMemcpyAsync(h->d_nominal, u, (size_t)h->R * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_get_nominal(ccv_mppi_handle* h, double* u) {
+    if (!h || !u) return CCV_MPPI_ERR_INVALID_ARG;
+    HIP_TRY(h, hipMemcpyAsync(u, h->d_nominal, (size_t)h->R * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_iterate(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref, const double* y_ref,
+                     double yaw_ref0, uint64_t seed, uint64_t iter, double* u_opt_out, ccv_mppi_stats* stats) {
+    int rc = check_iter_args(h, x0, dt, x_ref, y_ref);
+    if (rc) return rc;
+    rc = enqueue_iteration(h, x0, dt, x_ref, y_ref, yaw_ref0, seed, iter, true, nullptr);
+    if (rc) return rc;
+    return fetch_result(h, u_opt_out, stats);
+}
+
+int ccv_mppi_iterate_enqueue(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref, const double* y_ref,
+                             double yaw_ref0, uint64_t seed, uint64_t iter) {
+    int rc = check_iter_args(h, x0, dt, x_ref, y_ref);
+    if (rc) return rc;
+    return enqueue_iteration(h, x0, dt, x_ref, y_ref, yaw_ref0, seed, iter, true, nullptr);
+}
+
+int ccv_mppi_partials_size(const ccv_mppi_handle* h) { return h ? h->R + 1 : CCV_MPPI_ERR_INVALID_ARG; }
+
+int ccv_mppi_iterate_partials_enqueue(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref,
+                                      const double* y_ref, double yaw_ref0, uint64_t seed, uint64_t iter,
+                                      double* dev_partials) {
+    int rc = check_iter_args(h, x0, dt, x_ref, y_ref);
+    if (rc) return rc;
+    if (!dev_partials) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "dev_partials is null");
+    if (h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT)
+        return fail(h, CCV_MPPI_ERR_INVALID_ARG, "MIN_SHIFT needs a cross-device min; not supported with partials");
+    return enqueue_iteration(h, x0, dt, x_ref, y_ref, yaw_ref0, seed, iter, false, dev_partials);
+}
+
+int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partials) {
+    if (!h || !dev_partials) return CCV_MPPI_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_apply_partials, dim3(1), dim3(kBlock), 0, h->stream, dev_partials, h->d_nominal, h->d_stats, h->R);
+    HIP_TRY(h, hipGetLastError());
+    return CCV_MPPI_OK;
+}
+
+// ---- stage-wise -------------------------------------------------------------------------------------------------
+
+int ccv_mppi_sample(ccv_mppi_handle* h, uint64_t seed, uint64_t iter) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    RolloutArgs A;
+    const double zero[5] = {0, 0, 0, 0, 0};
+    fill_args(h, A, zero, 0.1, 0.0, seed, iter);
+    int rc = launch_sample(h, A);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_controls = true;
+    h->have_rollout = h->have_weights = false;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_inject_controls(ccv_mppi_handle* h, const double* u_samples) {
+    if (!h || !u_samples) return CCV_MPPI_ERR_INVALID_ARG;
+    // [K][(H-1)][u_dim] -> rows n = t*u_dim + d of pitch doubles
+    std::vector<double> tmp((size_t)h->R * h->pitch, 0.0);
+    for (int i = 0; i < h->K; ++i)
+        for (int n = 0; n < h->R; ++n) tmp[(size_t)n * h->pitch + i] = u_samples[(size_t)i * h->R + n];
+    HIP_TRY(h, hipMemcpyAsync(h->d_u, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_controls = true;
+    h->have_rollout = h->have_weights = false;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_rollout(ccv_mppi_handle* h, const double* x0, double dt) {
+    if (!h || !x0) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!h->have_controls) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_rollout before ccv_mppi_sample/inject_controls");
+    RolloutArgs A;
+    Window W;
+    std::memset(&W, 0, sizeof(W));
+    fill_args(h, A, x0, dt, 0.0, 0, 0);
+    A.store_u = 0;
+    A.store_xy = 1;
+    A.do_cost = 0;
+    int rc = launch_rollout(h, A, W, SRC_BUFFER);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::memcpy(h->st_x0, A.x0, sizeof(h->st_x0));
+    h->st_dt = dt;
+    h->have_rollout = true;
+    h->have_weights = false;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_weights(ccv_mppi_handle* h, const double* x_ref, const double* y_ref, double yaw_ref0) {
+    if (!h || !x_ref || !y_ref) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!h->have_rollout) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_weights before ccv_mppi_rollout");
+    RolloutArgs A;
+    Window W;
+    fill_args(h, A, h->st_x0, h->st_dt, yaw_ref0, 0, 0);
+    fill_window(h, W, h->st_x0, x_ref, y_ref);
+    A.store_u = 0;
+    A.store_xy = 0;
+    A.do_cost = 1;
+    // the rollout is recomputed from the stored controls (bit-identical to the stored states) and scored
+    int rc = launch_rollout(h, A, W, SRC_BUFFER);
+    if (rc) return rc;
+    // sum of weights (calc_Weights normalises, dd:222) without touching u*
+    rc = launch_update(h, false, nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_weights = true;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_update(ccv_mppi_handle* h, double* u_opt_out, ccv_mppi_stats* stats) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!h->have_weights) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_update before ccv_mppi_weights");
+    int rc = launch_update(h, true, nullptr);
+    if (rc) return rc;
+    return fetch_result(h, u_opt_out, stats);
+}
+
+// ---- read-back --------------------------------------------------------------------------------------------------
+
+int ccv_mppi_read_candidates(ccv_mppi_handle* h, int32_t first, int32_t count, int32_t stride, double* xy_out) {
+    if (!h || !xy_out || first < 0 || count < 0 || stride < 1) return CCV_MPPI_ERR_INVALID_ARG;
+    if (h->cfg.flags & CCV_MPPI_FLAG_NO_STATE_STORE) return fail(h, CCV_MPPI_ERR_STATE, "state buffer disabled (NO_STATE_STORE)");
+    if (!h->have_rollout) return fail(h, CCV_MPPI_ERR_STATE, "no rollout yet");
+    if (count == 0) return CCV_MPPI_OK;
+    if ((int64_t)first + (int64_t)(count - 1) * stride >= h->K) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "candidate range exceeds num_samples");
+    const size_t n = (size_t)count * h->H * 2;
+    int rc = ensure_scratch(h, n * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gather_xy, dim3((count * h->H + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_xs, h->d_ys,
+                       h->pitch, h->H, first, count, stride, h->d_scratch);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(xy_out, h->d_scratch, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CCV_MPPI_OK;
+}
+
+static int check_range(ccv_mppi_handle* h, int32_t first, int32_t count, const void* out) {
+    if (!h || !out || first < 0 || count < 0) return CCV_MPPI_ERR_INVALID_ARG;
+    if ((int64_t)first + count > h->K) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "range exceeds num_samples");
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_read_costs(ccv_mppi_handle* h, int32_t first, int32_t count, double* out) {
+    int rc = check_range(h, first, count, out);
+    if (rc) return rc;
+    if (!h->have_weights) return fail(h, CCV_MPPI_ERR_STATE, "no costs yet");
+    HIP_TRY(h, hipMemcpyAsync(out, h->d_cost + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_read_weights(ccv_mppi_handle* h, int32_t first, int32_t count, double* out) {
+    int rc = check_range(h, first, count, out);
+    if (rc) return rc;
+    if (!h->have_weights) return fail(h, CCV_MPPI_ERR_STATE, "no weights yet");
+    if (count == 0) return CCV_MPPI_OK;
+    rc = ensure_scratch(h, (size_t)count * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_normalise_weights, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_w, h->d_stats,
+                       first, count, h->d_scratch);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out, h->d_scratch, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_read_controls(ccv_mppi_handle* h, int32_t first, int32_t count, double* out) {
+    int rc = check_range(h, first, count, out);
+    if (rc) return rc;
+    if (!h->have_controls) return fail(h, CCV_MPPI_ERR_STATE, "no controls yet");
+    if (count == 0) return CCV_MPPI_OK;
+    std::vector<double> tmp((size_t)h->R * count);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy2D(tmp.data(), (size_t)count * sizeof(double), h->d_u + first, (size_t)h->pitch * sizeof(double),
+                           (size_t)count * sizeof(double), (size_t)h->R, hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; ++i)
+        for (int n = 0; n < h->R; ++n) out[(size_t)i * h->R + n] = tmp[(size_t)n * count + i];
+    return CCV_MPPI_OK;
+}
+
+// ---- measurement ------------------------------------------------------------------------------------------------
+
+int ccv_mppi_timing_enable(ccv_mppi_handle* h, int32_t on) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    int rc = timing_collect(h);
+    if (rc) return rc;
+    h->timing = on != 0;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_timing_read(ccv_mppi_handle* h, double* rollout_us_sum, double* iter_us_sum, int64_t* n_iters, int32_t reset) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    int rc = timing_collect(h);
+    if (rc) return rc;
+    if (rollout_us_sum) *rollout_us_sum = h->t_roll_sum;
+    if (iter_us_sum) *iter_us_sum = h->t_iter_sum;
+    if (n_iters) *n_iters = h->t_n;
+    if (reset) {
+        h->t_roll_sum = h->t_iter_sum = 0.0;
+        h->t_n = 0;
+    }
+    return CCV_MPPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Host prologue of the MPPI path (include/ccv_mppi_host.h): window builder, synthetic paths, kinematic plant.
+// Plain C++; no device work.  Reference locations are cited in the header.
+#include "../../include/ccv_mppi_host.h"
+
+#include <cmath>
+
+#include "../../include/ccv_mppi.h"
+
+namespace {
+
+// nearest pose of the path, accepted only inside a 100 m gate; 0 when nothing qualifies (dd:126-140)
+int nearest_index(const double* px, const double* py, int n, double x, double y) {
+    int best = 0;
+    double best_d = 100.0;
+    for (int i = 0; i < n; ++i) {
+        const double ex = x - px[i], ey = y - py[i];
+        const double d = std::sqrt(ex * ex + ey * ey);
+        if (d < best_d) {
+            best_d = d;
+            best = i;
+        }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccv_mppi_calc_ref_path(const double* path_x, const double* path_y, int32_t n_path, double cur_x, double cur_y,
+                           double v_ref, double dt, double resolution, int32_t horizon, double* x_ref, double* y_ref,
+                           double* yaw_ref) {
+    if (!path_x || !path_y || !x_ref || !y_ref || !yaw_ref || n_path < 1 || horizon < 2) return CCV_MPPI_ERR_INVALID_ARG;
+    const int start = nearest_index(path_x, path_y, n_path, cur_x, cur_y);
+    // window stride in path indices; the index is the truncation of a double (dd:160-163)
+    const double stride = v_ref * dt / resolution;
+    const int last = n_path - 1;
+    for (int i = 0; i < horizon; ++i) {
+        const int idx = static_cast<int>(start + i * stride);
+        const int src = idx < n_path ? idx : last;  // past the end: repeat the final pose (dd:169-172)
+        x_ref[i] = path_x[src];
+        y_ref[i] = path_y[src];
+    }
+    for (int i = 0; i + 1 < horizon; ++i) yaw_ref[i] = std::atan2(y_ref[i + 1] - y_ref[i], x_ref[i + 1] - x_ref[i]);
+    return start;
+}
+
+int ccv_mppi_path_cosine(const double* A, const double* omega, const double* delta, double resolution,
+                         double course_length, double init_x, double init_y, double* path_x, double* path_y,
+                         int32_t cap) {
+    if (!A || !omega || !delta || !path_x || !path_y || !(resolution > 0.0)) return CCV_MPPI_ERR_INVALID_ARG;
+    int n = 0;
+    // the arc parameter is accumulated, not multiplied, so the pose count follows the reference's rounding
+    for (double s = 0.0; s < course_length && n < cap; s += resolution, ++n) {
+        double y = A[0] * std::cos(2 * M_PI * omega[0] * s + delta[0]) + A[1] * std::cos(2 * M_PI * omega[1] * s + delta[1]) +
+                   A[2] * std::cos(2 * M_PI * omega[2] * s + delta[2]) + init_y;
+        y -= A[0] + A[1] + A[2];
+        path_x[n] = init_x + s;
+        path_y[n] = y;
+    }
+    return n;
+}
+
+int ccv_mppi_path_dkan(double resolution, double* path_x, double* path_y, int32_t cap) {
+    if (!path_x || !path_y || !(resolution > 0.0)) return CCV_MPPI_ERR_INVALID_ARG;
+    static const double corner[4][2] = {{0.0, 0.0}, {17.7, 0.0}, {17.7, 8.0}, {0.0, 8.0}};
+    int n = 0;
+    for (int leg = 0; leg < 3; ++leg) {
+        const double dx = corner[leg + 1][0] - corner[leg][0];
+        const double dy = corner[leg + 1][1] - corner[leg][1];
+        const double len = std::sqrt(dx * dx + dy * dy);
+        for (double s = 0.0; s < len; s += resolution) {
+            if (n >= cap) return n;
+            path_x[n] = corner[leg][0] + s * dx / len;
+            path_y[n] = corner[leg][1] + s * dy / len;
+            ++n;
+        }
+    }
+    return n;
+}
+
+int ccv_mppi_plant_step(int32_t model, double* state, const double* u, double dt) {
+    if (!state || !u || model < CCV_MPPI_DIFF_DRIVE || model > CCV_MPPI_FULL_BODY) return CCV_MPPI_ERR_INVALID_ARG;
+    const double heading = model == CCV_MPPI_DIFF_DRIVE ? state[2] : state[2] + u[2];
+    state[0] = state[0] + u[0] * std::cos(heading) * dt;
+    state[1] = state[1] + u[0] * std::sin(heading) * dt;
+    state[2] = state[2] + u[1] * dt;
+    if (model == CCV_MPPI_FULL_BODY) {
+        state[3] = state[3] + u[3] * dt;
+        state[4] = state[4] + u[4] * dt;
+    }
+    return CCV_MPPI_OK;
+}
+
+}  // extern "C"

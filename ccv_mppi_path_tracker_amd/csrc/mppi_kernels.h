@@ -1,0 +1,461 @@
+// HIP kernels of the MPPI hot path for gfx950 (MI355X).  Hand-written, wave64, one sample per lane.
+//
+//   k_rollout_cost   sampling() + predict_States() + calc_Cost()/calc_MinDistance() + exp   (dd:81-124,183-221;
+//                    sd:97-140,199-237; fb:394-424,445-520)
+//   k_update_partials / k_finalize / k_apply_partials    calc_Weights() normalisation + determine_OptimalSolution()
+//                    (dd:216-237, sd:232-255, fb:437-326)
+//   k_sample         stand-alone sampling() for the stage-wise ABI
+//   k_gather_xy      strided read-back feeding publish_CandidatePath() (dd:265-294)
+//
+// Data layout in HBM (all fp64, k fastest => every store/load of a wave is one contiguous 512-byte run):
+//   u    [(H-1)*u_dim][pitch]   row n = t*u_dim + d  clamped sample controls (sample[i].v_[t] ... in the reference)
+//   xs,ys[H][pitch]             sample[i].x_[t], sample[i].y_[t]
+//   cost [pitch], w [pitch]     per-sample cost and unnormalised weight exp(-cost/lambda)
+//   nominal [(H-1)*u_dim]       optimal_solution controls (resident warm start)
+// pitch = K rounded up to 64.  Compiled with -ffp-contract=off: a*b+c is fused only where fma() is written.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "../../include/ccv_mppi.h"
+#include "noise_spec.h"
+
+namespace ccv {
+
+constexpr int kMaxH = CCV_MPPI_MAX_HORIZON;
+constexpr int kTU = 8;        // time steps per register block (kTU*u_dim is a multiple of 4 normals for every model)
+constexpr int kBlock = 256;   // 4 waves: one per SIMD of a CU
+constexpr int kChunk = 2048;  // samples per k_update_partials block
+
+enum : int { SRC_PHILOX = 0, SRC_BUFFER = 1 };
+
+__host__ __device__ constexpr int udim_of(int model) { return model == 0 ? 2 : (model == 1 ? 3 : 5); }
+
+// Window coefficients: squared distance to window point j is |p|^2 + a_j*px + b_j*py + c_j with p relative to the
+// current pose.  Travels in the kernel-argument segment (wave-uniform => scalar loads).
+struct Window {
+    double a[kMaxH];
+    double b[kMaxH];
+    double c[kMaxH];
+};
+
+struct RolloutArgs {
+    double x0[5];
+    double dt;
+    double yaw_ref0;
+    double sigma, lambda, v_ref;
+    double umin[5], umax[5];
+    double w_path, w_v, w_zmp, w_rollv, w_back, w_yaw;
+    double fb_mass, fb_L, fb_Ixx, fb_gz;  // fb.h:212-216, fb:86-91, fb.h:30
+    uint32_t seed_lo, seed_hi, iter_lo, iter_hi;
+    int32_t K, pitch, H, k_offset;
+    int32_t steer_off, store_u, store_xy, do_cost;
+    const double* nominal;
+    double* u;
+    double* xs;
+    double* ys;
+    double* cost;
+    double* w;
+};
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// dd:62-67
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// min over the H window points of (a_j*px + b_j*py + c_j) for NV trajectory points held in registers.
+// 2 FMA + 1 MIN per (point, window point): the O(K*H^2) core (calc_MinDistance, dd:183-192).
+template <int NV, bool LDSWIN>
+__device__ __forceinline__ void window_min(const double (&px)[kTU], const double (&py)[kTU], double (&m)[kTU], int H,
+                                           const Window& W, const double2* s_ab, const double* s_c) {
+#pragma unroll 2
+    for (int j = 0; j < H; ++j) {
+        double a, b, c;
+        if constexpr (LDSWIN) {
+            const double2 ab = s_ab[j];
+            a = ab.x;
+            b = ab.y;
+            c = s_c[j];
+        } else {
+            a = W.a[j];
+            b = W.b[j];
+            c = W.c[j];
+        }
+        static_for<NV>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            m[i] = fmin(m[i], fma(a, px[i], fma(b, py[i], c)));
+        });
+    }
+}
+
+template <int MODEL, int SRC, bool LDSWIN>
+__global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, const Window W) {
+    constexpr int UD = udim_of(MODEL);
+    __shared__ double2 s_ab[LDSWIN ? kMaxH : 1];
+    __shared__ double s_c[LDSWIN ? kMaxH : 1];
+    const int H = A.H;
+    if constexpr (LDSWIN) {
+        for (int j = threadIdx.x; j < H; j += kBlock) {
+            s_ab[j] = make_double2(W.a[j], W.b[j]);
+            s_c[j] = W.c[j];
+        }
+        __syncthreads();
+    }
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = k < A.K;
+    const int kk = live ? k : A.K - 1;
+    const size_t pitch = (size_t)A.pitch;
+    const double dt = A.dt;
+    const uint32_t kg = (uint32_t)(A.k_offset + kk);
+
+    double x = A.x0[0], y = A.x0[1], yaw = A.x0[2];
+    double roll = A.x0[3], pitchang = A.x0[4];
+    double cost = 0.0;
+    if constexpr (MODEL == CCV_MPPI_FULL_BODY) {
+        // fb:408 -- identical for every sample
+        cost += A.w_yaw * (yaw - A.yaw_ref0) * (yaw - A.yaw_ref0);
+    }
+    // full-body carry from step t-1 (the ZMP term of index t-1 needs controls t-1 and t, fb:468-486)
+    double p_v = 0.0, p_rv = 0.0, p_sdir = 0.0, p_cdir = 1.0, p_c2 = 0.0, p_c3 = 0.0, p_ac = 0.0;
+    const double fb_mgz = A.fb_mass * A.fb_gz;    // (mass*gravity_).z
+    const double fb_den = A.fb_mass * A.fb_gz;    // mass*(gravity_-accel).dot(z); accel.z == 0 (fb:475,601)
+
+    for (int t0 = 0; t0 < H; t0 += kTU) {
+        double px[kTU], py[kTU];
+        float zq[4] = {0.f, 0.f, 0.f, 0.f};
+        static_for<kTU>([&](auto TT) {
+            constexpr int tt = decltype(TT)::value;
+            const int t = t0 + tt;
+            px[tt] = x - A.x0[0];
+            py[tt] = y - A.x0[1];
+            if (t < H) {
+                if (A.store_xy && live) {
+                    A.xs[(size_t)t * pitch + k] = x;
+                    A.ys[(size_t)t * pitch + k] = y;
+                }
+                if (t < H - 1) {
+                    double u[UD];
+                    static_for<UD>([&](auto D) {
+                        constexpr int d = decltype(D)::value;
+                        constexpr int nloc = tt * UD + d;
+                        const size_t row = (size_t)(t * UD + d);
+                        if constexpr (SRC == SRC_PHILOX) {
+                            if constexpr ((nloc & 3) == 0) {
+                                const Philox4 r = philox4x32_10(kg, (uint32_t)((t0 * UD + nloc) >> 2), A.iter_lo,
+                                                                A.iter_hi, A.seed_lo, A.seed_hi);
+                                box_muller_f32(r.x, r.y, zq[0], zq[1]);
+                                box_muller_f32(r.z, r.w, zq[2], zq[3]);
+                            }
+                            // libstdc++ normal_distribution: ret * stddev + mean (dd:96-97), then clamp (dd:98-99)
+                            double v = (double)zq[nloc & 3] * A.sigma + A.nominal[row];
+                            v = clampd(v, A.umin[d], A.umax[d]);
+                            if constexpr (MODEL == CCV_MPPI_FULL_BODY && d == 2) {
+                                if (A.steer_off) v = 0.0;  // fb:517
+                            }
+                            u[d] = v;
+                            if (A.store_u && live) A.u[row * pitch + k] = v;
+                        } else {
+                            u[d] = A.u[row * pitch + kk];
+                        }
+                    });
+                    // ---- cost terms that do not need the window ----
+                    if (A.do_cost) {
+                        if constexpr (MODEL != CCV_MPPI_FULL_BODY) {
+                            cost += A.w_v * ((u[0] - A.v_ref) * (u[0] - A.v_ref));  // dd:204-206
+                        } else {
+                            if (t < H - 2) {  // fb:409
+                                cost += A.w_v * (u[0] - A.v_ref) * (u[0] - A.v_ref);          // fb:413
+                                if (u[0] < 0.0) cost += A.w_back * u[0] * u[0];               // fb:420
+                            }
+                            if (t >= 1) {  // finish index t-1 <= H-3: ZMP (fb:468-485, 597-603) and roll-rate terms
+                                const double drive_accel = (u[0] - p_v) / dt;                  // fb:469
+                                const double ay = drive_accel * p_sdir + p_ac * p_cdir;        // fb:473
+                                const double hgdot_x = (A.fb_Ixx * u[3] - A.fb_Ixx * p_rv) / dt;  // fb:479-481
+                                const double mo_x = (p_c2 * fb_mgz + p_c3 * (A.fb_mass * ay)) - hgdot_x;  // fb:600
+                                const double zmp_y = mo_x / fb_den;                            // fb:601
+                                cost += A.w_zmp * zmp_y * zmp_y;                               // fb:416
+                                cost += A.w_rollv * (u[3] - p_rv) * (u[3] - p_rv);             // fb:418
+                            }
+                        }
+                    }
+                    // ---- dynamics: explicit Euler (dd:104-109, sd:120-125, fb:445-452) ----
+                    double hd = yaw;
+                    if constexpr (MODEL != CCV_MPPI_DIFF_DRIVE) hd = yaw + u[2];
+                    double sn, cs;
+                    sincos(hd, &sn, &cs);
+                    if constexpr (MODEL == CCV_MPPI_FULL_BODY) {
+                        if (A.do_cost) {
+                            double sd_, cd_, sr_, cr_;
+                            sincos(u[2], &sd_, &cd_);
+                            sincos(roll, &sr_, &cr_);
+                            p_sdir = sd_;
+                            p_cdir = cd_;
+                            p_c2 = -A.fb_L * sr_;                      // CoM.y (fb:482)
+                            p_c3 = A.fb_L * cos(pitchang) * cr_;       // CoM.z
+                            p_ac = u[0] * u[1];                        // fb:471
+                            p_v = u[0];
+                            p_rv = u[3];
+                        }
+                    }
+                    x = x + u[0] * cs * dt;
+                    y = y + u[0] * sn * dt;
+                    yaw = yaw + u[1] * dt;
+                    if constexpr (MODEL == CCV_MPPI_FULL_BODY) {
+                        roll = roll + u[3] * dt;
+                        pitchang = pitchang + u[4] * dt;
+                    }
+                } else {
+                    if constexpr (MODEL != CCV_MPPI_FULL_BODY) {
+                        // t == H-1: the reference reads control index H-1, one past the end (dd:199,204); defined
+                        // semantics: that element is 0.0
+                        if (A.do_cost) cost += A.w_v * ((0.0 - A.v_ref) * (0.0 - A.v_ref));
+                    }
+                }
+            }
+        });
+        if (A.do_cost) {
+            // states that reach the path cost: all H for dd/sd (dd:199), the first H-2 for fb (fb:409)
+            const int nstates = (MODEL == CCV_MPPI_FULL_BODY) ? H - 2 : H;
+            const int nv = min(kTU, nstates - t0);
+            if (nv > 0) {
+                double m[kTU];
+#pragma unroll
+                for (int i = 0; i < kTU; ++i) m[i] = INFINITY;
+                switch (nv) {
+                    case 8: window_min<8, LDSWIN>(px, py, m, H, W, s_ab, s_c); break;
+                    case 7: window_min<7, LDSWIN>(px, py, m, H, W, s_ab, s_c); break;
+                    case 6: window_min<6, LDSWIN>(px, py, m, H, W, s_ab, s_c); break;
+                    case 5: window_min<5, LDSWIN>(px, py, m, H, W, s_ab, s_c); break;
+                    case 4: window_min<4, LDSWIN>(px, py, m, H, W, s_ab, s_c); break;
+                    case 3: window_min<3, LDSWIN>(px, py, m, H, W, s_ab, s_c); break;
+                    case 2: window_min<2, LDSWIN>(px, py, m, H, W, s_ab, s_c); break;
+                    default: window_min<1, LDSWIN>(px, py, m, H, W, s_ab, s_c); break;
+                }
+#pragma unroll
+                for (int i = 0; i < kTU; ++i) {
+                    if (i < nv) {
+                        // d^2 = |p|^2 + min_j(...), gate d <= 100 (dd:185), cost += path_weight*d*d (dd:206)
+                        double d2 = m[i] + fma(px[i], px[i], py[i] * py[i]);
+                        d2 = fmin(fmax(d2, 0.0), 1.0e4);
+                        cost += A.w_path * d2;
+                    }
+                }
+            }
+        }
+    }
+    if (A.do_cost && live) {
+        A.cost[k] = cost;
+        A.w[k] = exp(-cost / A.lambda);  // dd:219 (no min-cost shift)
+    }
+}
+
+// stand-alone sampling(): one thread per (sample, Philox call) -> 4 consecutive rows of u.
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_sample(const RolloutArgs A) {
+    constexpr int UD = udim_of(MODEL);
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    const int call = blockIdx.y;
+    if (k >= A.K) return;
+    const int ntot = (A.H - 1) * UD;
+    const Philox4 r = philox4x32_10((uint32_t)(A.k_offset + k), (uint32_t)call, A.iter_lo, A.iter_hi, A.seed_lo, A.seed_hi);
+    float z[4];
+    box_muller_f32(r.x, r.y, z[0], z[1]);
+    box_muller_f32(r.z, r.w, z[2], z[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = call * 4 + i;
+        if (n < ntot) {
+            const int d = n % UD;
+            double v = (double)z[i] * A.sigma + A.nominal[n];
+            v = clampd(v, A.umin[d], A.umax[d]);
+            if (MODEL == CCV_MPPI_FULL_BODY && d == 2 && A.steer_off) v = 0.0;
+            A.u[(size_t)n * A.pitch + k] = v;
+        }
+    }
+}
+
+// ---- weighted update -------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+struct UpdateArgs {
+    const double* u;
+    const double* w;
+    const double* cost;
+    double* partial;   // [(R+1)][nchunks]
+    double* statpart;  // [nchunks][3]: min cost, max cost, zero-weight count
+    int32_t K, pitch, R, nchunks;
+};
+
+// grid (nchunks, R+1).  Row n < R: sum_k w_k*u[n][k] over this chunk; row R: sum_k w_k (+ cost stats).
+// Fixed reduction order => bitwise reproducible (no atomics).
+__global__ __launch_bounds__(kBlock) void k_update_partials(const UpdateArgs A) {
+    __shared__ double red[4][4];
+    const int row = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int base = chunk * kChunk;
+    const bool wrow = row == A.R;
+    const double* urow = A.u + (size_t)row * A.pitch;
+    double acc = 0.0, mn = INFINITY, mx = -INFINITY, nz = 0.0;
+#pragma unroll
+    for (int i = 0; i < kChunk / (2 * kBlock); ++i) {
+        const int k = base + i * 2 * kBlock + threadIdx.x * 2;
+        if (k + 1 < A.K) {
+            const double2 wv = *reinterpret_cast<const double2*>(A.w + k);
+            if (wrow) {
+                acc += wv.x;
+                acc += wv.y;
+                const double2 cv = *reinterpret_cast<const double2*>(A.cost + k);
+                mn = fmin(mn, fmin(cv.x, cv.y));
+                mx = fmax(mx, fmax(cv.x, cv.y));
+                nz += (wv.x == 0.0 ? 1.0 : 0.0) + (wv.y == 0.0 ? 1.0 : 0.0);
+            } else {
+                const double2 uv = *reinterpret_cast<const double2*>(urow + k);
+                acc += wv.x * uv.x;
+                acc += wv.y * uv.y;
+            }
+        } else if (k < A.K) {
+            const double wv = A.w[k];
+            if (wrow) {
+                acc += wv;
+                const double cv = A.cost[k];
+                mn = fmin(mn, cv);
+                mx = fmax(mx, cv);
+                nz += (wv == 0.0 ? 1.0 : 0.0);
+            } else {
+                acc += wv * urow[k];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    acc = wave_sum(acc);
+    if (wrow) {
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        nz = wave_sum(nz);
+    }
+    if (lane == 0) {
+        red[0][wid] = acc;
+        red[1][wid] = mn;
+        red[2][wid] = mx;
+        red[3][wid] = nz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        A.partial[(size_t)row * A.nchunks + chunk] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        if (wrow) {
+            A.statpart[chunk * 3 + 0] = fmin(fmin(red[1][0], red[1][1]), fmin(red[1][2], red[1][3]));
+            A.statpart[chunk * 3 + 1] = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+            A.statpart[chunk * 3 + 2] = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+        }
+    }
+}
+
+struct FinalizeArgs {
+    const double* partial;   // [(R+1)][nchunks]
+    const double* statpart;  // [nchunks][3]
+    double* nominal;         // [R]      (mode 0)
+    double* vec;             // [1+R]    unnormalised [sum w, sum w*u] (always written)
+    double* stats;           // [4]      sum_w, min cost, max cost, zero-weight count
+    int32_t R, nchunks, normalise;
+};
+
+// One block.  Thread n sums the chunk partials of row n in ascending chunk order; u*[n] = V_n / S
+// (== sum_i (w_i/S) u_i of dd:222,234 up to rounding; S == 0 gives NaN exactly as dd:222 does).
+__global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
+    __shared__ double s_sum;
+    if (threadIdx.x == 0) {
+        double s = 0.0, mn = INFINITY, mx = -INFINITY, nz = 0.0;
+        for (int c = 0; c < A.nchunks; ++c) {
+            s += A.partial[(size_t)A.R * A.nchunks + c];
+            mn = fmin(mn, A.statpart[c * 3 + 0]);
+            mx = fmax(mx, A.statpart[c * 3 + 1]);
+            nz += A.statpart[c * 3 + 2];
+        }
+        s_sum = s;
+        A.vec[0] = s;
+        A.stats[0] = s;
+        A.stats[1] = mn;
+        A.stats[2] = mx;
+        A.stats[3] = nz;
+    }
+    __syncthreads();
+    const double S = s_sum;
+    for (int n = threadIdx.x; n < A.R; n += kBlock) {
+        double v = 0.0;
+        for (int c = 0; c < A.nchunks; ++c) v += A.partial[(size_t)n * A.nchunks + c];
+        A.vec[1 + n] = v;
+        if (A.normalise) A.nominal[n] = v / S;
+    }
+}
+
+// After the cross-device all-reduce of [sum w, sum w*u]: u* = V / S on every device.
+__global__ __launch_bounds__(kBlock) void k_apply_partials(const double* vec, double* nominal, double* stats, int R) {
+    const double S = vec[0];
+    if (threadIdx.x == 0) stats[0] = S;
+    for (int n = threadIdx.x; n < R; n += kBlock) nominal[n] = vec[1 + n] / S;
+}
+
+// ---- optional underflow-safe weights (CCV_MPPI_FLAG_MIN_SHIFT; not reference behaviour) --------------------------
+__global__ __launch_bounds__(1024) void k_min_cost(const double* cost, int K, double* out_min) {
+    __shared__ double red[16];
+    double mn = INFINITY;
+    for (int k = threadIdx.x; k < K; k += 1024) mn = fmin(mn, cost[k]);
+    mn = wave_min(mn);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = red[0];
+        for (int i = 1; i < 16; ++i) r = fmin(r, red[i]);
+        *out_min = r;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_reweight(const double* cost, const double* cmin, double lambda, int K, double* w) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < K) w[k] = exp(-(cost[k] - *cmin) / lambda);
+}
+
+// ---- read-back helpers -----------------------------------------------------------------------------------------
+// out[c][t][2] = (xs[t][first + c*stride], ys[t][...])
+__global__ __launch_bounds__(kBlock) void k_gather_xy(const double* xs, const double* ys, int pitch, int H, int first,
+                                                      int count, int stride, double* out) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= count * H) return;
+    const int c = idx / H, t = idx % H;
+    const size_t src = (size_t)t * pitch + first + (size_t)c * stride;
+    out[(size_t)idx * 2 + 0] = xs[src];
+    out[(size_t)idx * 2 + 1] = ys[src];
+}
+
+__global__ __launch_bounds__(kBlock) void k_normalise_weights(const double* w, const double* stats, int first, int count,
+                                                             double* out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < count) out[i] = w[first + i] / stats[0];
+}
+
+}  // namespace ccv

@@ -1,0 +1,99 @@
+// Counter-based control noise for the MI355X MPPI path (DESIGN.md "Noise spec").
+//
+// Replaces std::mt19937 + std::normal_distribution of the reference's sampling()
+// (src/diff_drive_mppi.cpp:83-97): that generator is a single serial stream with a
+// data-dependent number of engine words per variate (polar rejection), which cannot be
+// drawn one-sample-per-lane.  Here normal number n = t*u_dim + d of global sample k in
+// iteration `iter` is a pure function of (seed, iter, k, n):
+//
+//   words = Philox4x32-10(counter = {k, n/4, iter_lo, iter_hi}, key = {seed_lo, seed_hi})
+//   (z[4c+0], z[4c+1]) = box_muller_f32(words[0], words[1]);  (z[4c+2], z[4c+3]) = box_muller_f32(words[2], words[3])
+//
+// box_muller_f32 uses only integer ops and correctly rounded IEEE fp32 add/mul/fma/sqrt with
+// fixed polynomial coefficients, so a CPU restatement (oracle/philox_normal.h, test-only)
+// reproduces every bit.  Build with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ccv {
+
+struct Philox4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        // one 32x32->64 multiply per lane pair (v_mad_u64_u32) instead of mul_lo + mul_hi
+        const unsigned long long pa = (unsigned long long)c0 * 0xD2511F53ull;
+        const unsigned long long pb = (unsigned long long)c2 * 0xCD9E8D57ull;
+        const uint32_t n0 = (uint32_t)(pb >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(pa >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)pb;
+        c3 = (uint32_t)pa;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+// -log2 polynomial, sin/cos polynomials: tools/fit_normal_polys.py
+#define CCV_Q0 0x1.715476p+0f
+#define CCV_Q1 -0x1.715476p-1f
+#define CCV_Q2 0x1.ec73e0p-2f
+#define CCV_Q3 -0x1.715946p-2f
+#define CCV_Q4 0x1.26cfb8p-2f
+#define CCV_Q5 -0x1.e9df04p-3f
+#define CCV_Q6 0x1.ba9caap-3f
+#define CCV_Q7 -0x1.a548fcp-3f
+#define CCV_Q8 0x1.f702acp-4f
+
+// (a, b) -> two N(0,1) variates at fp32 resolution.  r = sqrt(-2 ln u1), u1 = max(a,1)/2^32;
+// theta = (pi/2)*(quadrant + centred 30-bit fraction of b).
+__device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const uint32_t a1 = a == 0u ? 1u : a;
+    const int lz = __builtin_clz(a1);
+    const uint32_t m = a1 << lz;                      // u1 = m * 2^(-32-lz)
+    const bool fold = m > 0xB504F333u;                // mantissa > sqrt(2): use m/2^32 in [sqrt(.5),1), bump exponent
+    // t = mantissa - 1 from the integer: keeps full relative precision as u1 -> 1
+    const float t = fold ? -((float)(0u - m) * 0x1p-32f) : (float)(m - 0x80000000u) * 0x1p-31f;
+    const float L0 = (float)(1 + lz - (fold ? 1 : 0));
+    float q = CCV_Q8;
+    q = __builtin_fmaf(q, t, CCV_Q7);
+    q = __builtin_fmaf(q, t, CCV_Q6);
+    q = __builtin_fmaf(q, t, CCV_Q5);
+    q = __builtin_fmaf(q, t, CCV_Q4);
+    q = __builtin_fmaf(q, t, CCV_Q3);
+    q = __builtin_fmaf(q, t, CCV_Q2);
+    q = __builtin_fmaf(q, t, CCV_Q1);
+    q = __builtin_fmaf(q, t, CCV_Q0);
+    const float L = __builtin_fmaf(-t, q, L0);       // -log2(u1) >= 0
+    const float r = __builtin_sqrtf(L * 0x1.62e430p+0f);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+
+    const uint32_t quad = b >> 30;
+    const int32_t f = (int32_t)(b & 0x3FFFFFFFu) - (1 << 29);
+    const float al = (float)f * 0x1.921fb6p-30f;     // [-pi/4, pi/4)
+    const float w = al * al;
+    float s = 0x1.6dbc3ep-19f, c = 0x1.9a6a98p-16f;
+    s = __builtin_fmaf(s, w, -0x1.a013a2p-13f);
+    c = __builtin_fmaf(c, w, -0x1.6c0df8p-10f);
+    s = __builtin_fmaf(s, w, 0x1.11110ep-7f);
+    c = __builtin_fmaf(c, w, 0x1.55554cp-5f);
+    s = __builtin_fmaf(s, w, -0x1.555556p-3f);
+    c = __builtin_fmaf(c, w, -0x1.000000p-1f);
+    const float sn = __builtin_fmaf(al * w, s, al);
+    const float cs = __builtin_fmaf(w, c, 1.0f);
+    // rotate by quadrant: (cos,sin)(theta) for theta = quad*pi/2 + al
+    const float ca = (quad & 1u) ? sn : cs;
+    const float sa = (quad & 1u) ? cs : sn;
+    const float cq = (quad == 1u || quad == 2u) ? -ca : ca;
+    const float sq = (quad >= 2u) ? -sa : sa;
+    z0 = r * cq;
+    z1 = r * sq;
+}
+
+}  // namespace ccv

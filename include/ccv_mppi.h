@@ -1,0 +1,161 @@
+/*
+ * ccv_mppi.h -- C ABI of the MI355X-native MPPI hot path (libccv_mppi_hip.so).
+ *
+ * Drop-in boundary for the four hot methods of the reference controller classes of
+ * YoshikiMaekawa2000/ccv_mppi_path_tracker.  The reference has no FFI/plugin interface
+ * (SURVEY.md 8b): the seam is the bodies of the private methods
+ *
+ *     sampling()                    src/diff_drive_mppi.cpp:81-102   src/steering_diff_drive_mppi.cpp:97-118   src/full_body_mppi.cpp:491-520
+ *     predict_States()              src/diff_drive_mppi.cpp:111-124  src/steering_diff_drive_mppi.cpp:127-140  src/full_body_mppi.cpp:454-489
+ *     calc_Weights()                src/diff_drive_mppi.cpp:212-223  src/steering_diff_drive_mppi.cpp:228-239  src/full_body_mppi.cpp:426-443
+ *     determine_OptimalSolution()   src/diff_drive_mppi.cpp:225-246  src/steering_diff_drive_mppi.cpp:241-264  src/full_body_mppi.cpp:308-333
+ *
+ * called once each, in this order, from run() (src/diff_drive_mppi.cpp:352-358).  INTEGRATION.md
+ * shows the patch a maintainer applies to those method bodies.
+ *
+ * Conventions (mirroring the reference):
+ *   - plain C, no exceptions; every function returns an int status (0 = OK, <0 = error) and never aborts;
+ *   - an opaque handle owns all device memory, allocated once in ccv_mppi_create() (the reference allocates
+ *     everything once in the constructor, src/diff_drive_mppi.cpp:36-46) and never resized;
+ *   - the caller owns all host arrays; pointers are host pointers unless a parameter name starts with `dev_`;
+ *   - one handle = one caller thread; calls are blocking unless named *_async / *_enqueue;
+ *   - all floating point data is IEEE double (the reference computes in double throughout);
+ *   - there is NO CPU fallback: without a usable HIP device every call fails with CCV_MPPI_ERR_NO_DEVICE.
+ */
+#ifndef CCV_MPPI_H_
+#define CCV_MPPI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCV_MPPI_ABI_VERSION 1
+#define CCV_MPPI_MAX_UDIM 5
+#define CCV_MPPI_MAX_HORIZON 128 /* window coefficients travel in the kernel-argument segment */
+
+/* status codes */
+#define CCV_MPPI_OK 0
+#define CCV_MPPI_ERR_INVALID_ARG (-1)
+#define CCV_MPPI_ERR_NO_DEVICE (-2)
+#define CCV_MPPI_ERR_HIP (-3)
+#define CCV_MPPI_ERR_STATE (-4) /* stage-wise calls in the wrong order */
+#define CCV_MPPI_ERR_ALLOC (-5)
+
+/* controller model; u_dim = 2 / 3 / 5, control order = declaration order of the reference
+ * (dd: v,w  sd: v,w,steer  fb: v,w,direction,roll_v,pitch_v) */
+#define CCV_MPPI_DIFF_DRIVE 0
+#define CCV_MPPI_STEERING_DIFF_DRIVE 1
+#define CCV_MPPI_FULL_BODY 2
+
+/* flags */
+#define CCV_MPPI_FLAG_ROLL_OFF 0x1   /* src/full_body_mppi.cpp:43-46: zmp_weight = roll_v_weight = 0 */
+#define CCV_MPPI_FLAG_STEER_OFF 0x2  /* src/full_body_mppi.cpp:517: direction forced to 0 after the draw */
+#define CCV_MPPI_FLAG_MIN_SHIFT 0x4  /* NOT reference behaviour: w = exp(-(c - min c)/lambda) (underflow-safe) */
+#define CCV_MPPI_FLAG_NO_STATE_STORE 0x8 /* skip the K x H x,y state buffer (read_candidates then fails) */
+
+typedef struct ccv_mppi_config {
+    int32_t abi_version;        /* CCV_MPPI_ABI_VERSION */
+    int32_t model;              /* CCV_MPPI_DIFF_DRIVE ... */
+    int32_t num_samples;        /* K on THIS device (param "num_samples", dd:19) */
+    int32_t horizon;            /* H: number of states, H-1 control steps (param "horizon", dd:18); 3..CCV_MPPI_MAX_HORIZON */
+    int32_t sample_offset;      /* global id of local sample 0 when K is sharded over devices (0 otherwise) */
+    int32_t device;             /* HIP device ordinal */
+    int32_t flags;              /* CCV_MPPI_FLAG_* */
+    int32_t reserved;
+    double control_noise;       /* sigma, one value for every control dimension (dd:20) */
+    double lambda;              /* dd:21 */
+    double v_ref;               /* dd:28 */
+    double u_min[CCV_MPPI_MAX_UDIM]; /* clamp bounds per control dimension (dd:22-26, sd:23-28, fb:13-26) */
+    double u_max[CCV_MPPI_MAX_UDIM];
+    double path_weight;         /* dd:33 */
+    double v_weight;            /* dd:34 ("control_weight" in dd/sd, "v_weight" in fb:35) */
+    double zmp_weight;          /* fb:36 */
+    double roll_v_weight;       /* fb:37 */
+    double back_weight;         /* fb:38 */
+    double yaw_weight;          /* fb:39 */
+} ccv_mppi_config;
+
+typedef struct ccv_mppi_stats {
+    double sum_w;        /* sum_i exp(-cost_i/lambda) (unnormalised; 0 => u* is NaN exactly like dd:222) */
+    double min_cost;
+    double max_cost;
+    int64_t n_zero_weight; /* samples whose weight underflowed to exactly 0 */
+    int32_t nonfinite;   /* 1 if any component of the returned controls is NaN/Inf */
+    int32_t reserved;
+    float device_us;     /* device time of the last iteration's kernels (hipEvent), 0 if not measured */
+    float rollout_us;    /* device time of the dominant kernel (sample+rollout+cost) */
+} ccv_mppi_stats;
+
+typedef struct ccv_mppi_handle ccv_mppi_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+/* Replaces the allocation part of the constructors (dd:36-46, sd:38-48, fb:72-84). */
+int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out);
+int ccv_mppi_destroy(ccv_mppi_handle* h);
+/* Launch on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the handle's own stream. */
+int ccv_mppi_set_stream(ccv_mppi_handle* h, void* hip_stream);
+const char* ccv_mppi_last_error(const ccv_mppi_handle* h);
+const char* ccv_mppi_version(void);
+int ccv_mppi_udim(int model);
+
+/* ---- warm start: optimal_solution controls, layout [(H-1)][u_dim] (dd.h:100) -------- */
+int ccv_mppi_set_nominal(ccv_mppi_handle* h, const double* u);
+int ccv_mppi_get_nominal(ccv_mppi_handle* h, double* u);
+
+/* ---- one whole iteration: sampling + predict_States + calc_Weights + determine_OptimalSolution ---- */
+/* x0: (x, y, yaw[, roll, pitch]) = current_pose_/current_state_ (dd:115-117, fb:458-464); dt: dt_ (dd:347);
+ * x_ref/y_ref: the H window points written by calc_RefPath() (dd:156-181); yaw_ref0: yaw_ref_[0] (fb:408);
+ * seed/iter: counter-based noise key (the reference reseeds mt19937 from random_device every call, dd:83-84);
+ * u_opt_out: new optimal_solution controls [(H-1)][u_dim]; stats may be NULL. Blocking. */
+int ccv_mppi_iterate(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref, const double* y_ref,
+                     double yaw_ref0, uint64_t seed, uint64_t iter, double* u_opt_out, ccv_mppi_stats* stats);
+/* Same work, enqueued on the stream without any host synchronisation; u* stays resident on the device as the
+ * next call's warm start.  Read it back with ccv_mppi_get_nominal(). */
+int ccv_mppi_iterate_enqueue(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref,
+                             const double* y_ref, double yaw_ref0, uint64_t seed, uint64_t iter);
+int ccv_mppi_synchronize(ccv_mppi_handle* h);
+
+/* ---- stage-wise mirrors of the four reference methods (reference call order; parity tests) -------- */
+int ccv_mppi_sample(ccv_mppi_handle* h, uint64_t seed, uint64_t iter);                 /* sampling() */
+/* Parity hook: overwrite the sample controls with caller data [K][(H-1)][u_dim] (already clamped, e.g. the
+ * output of the reference's own sampling()); replaces ccv_mppi_sample for that iteration. */
+int ccv_mppi_inject_controls(ccv_mppi_handle* h, const double* u_samples);
+int ccv_mppi_rollout(ccv_mppi_handle* h, const double* x0, double dt);                  /* predict_States() */
+int ccv_mppi_weights(ccv_mppi_handle* h, const double* x_ref, const double* y_ref, double yaw_ref0); /* calc_Weights() */
+int ccv_mppi_update(ccv_mppi_handle* h, double* u_opt_out, ccv_mppi_stats* stats);     /* determine_OptimalSolution() */
+
+/* ---- read-back ------------------------------------------------------------------------------------ */
+/* Feeds publish_CandidatePath() (dd:265-294) without a K x H device-to-host copy: samples first, first+stride, ...
+ * (count of them); xy_out layout [count][H][2]. */
+int ccv_mppi_read_candidates(ccv_mppi_handle* h, int32_t first, int32_t count, int32_t stride, double* xy_out);
+int ccv_mppi_read_costs(ccv_mppi_handle* h, int32_t first, int32_t count, double* out);
+/* normalised weights w_i / sum_w, i.e. the reference's weights_ (dd:222) */
+int ccv_mppi_read_weights(ccv_mppi_handle* h, int32_t first, int32_t count, double* out);
+/* sample controls, layout [count][(H-1)][u_dim] */
+int ccv_mppi_read_controls(ccv_mppi_handle* h, int32_t first, int32_t count, double* out);
+
+/* ---- K sharded over several devices (one handle per device/process) ------------------ */
+/* Number of doubles in the per-device partial vector: 1 + (H-1)*u_dim = [sum w, sum w*u[t][d] ...]. */
+int ccv_mppi_partials_size(const ccv_mppi_handle* h);
+/* sample+rollout+cost+local reduction; leaves the unnormalised partials in dev_partials (DEVICE memory of this
+ * handle's device, e.g. a torch tensor) without touching u*.  The caller all-reduces (sum) dev_partials across
+ * devices (RCCL) on the same stream, then calls ccv_mppi_apply_partials on every device. No host sync. */
+int ccv_mppi_iterate_partials_enqueue(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref,
+                                      const double* y_ref, double yaw_ref0, uint64_t seed, uint64_t iter,
+                                      double* dev_partials);
+/* u* = partials[1:] / partials[0], written to the resident warm start (no host sync). */
+int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partials);
+
+/* ---- measurement ----------------------------------------------------------------------------------- */
+/* When enabled every iteration records hipEvents around the dominant kernel and the whole launch sequence;
+ * ccv_mppi_timing_read returns the accumulated device times since the last reset (it synchronises). */
+int ccv_mppi_timing_enable(ccv_mppi_handle* h, int32_t on);
+int ccv_mppi_timing_read(ccv_mppi_handle* h, double* rollout_us_sum, double* iter_us_sum, int64_t* n_iters,
+                         int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCV_MPPI_H_ */

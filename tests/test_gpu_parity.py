@@ -1,0 +1,403 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
+
+Parity chain (the reference itself cannot be built or run here, see DESIGN.md "Oracle"):
+  O->G   oracle in mt19937 mode (the reference's own generator) -> its clamped samples are INJECTED into the GPU
+         (ccv_mppi_inject_controls) -> rollout / cost / weights / update must match the oracle:
+         costs <= 1e-9 rel, u* <= 1e-5 rel (north_star tolerance; observed ~1e-12).
+  R'->G  oracle in philox mode vs GPU philox: noise bit-exact, u* <= 1e-5 rel (observed ~1e-10).
+Full BASELINE sizes are covered through size-independent properties (contiguous sample blocks re-scored by the
+oracle, host recomputation of the weighted mean, determinism, shard invariance).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+import ccv_mppi_path_tracker_amd as amd
+from ccv_mppi_path_tracker_amd import capi, configs
+from ccv_mppi_path_tracker_amd.controller import MPPIController, MPPIError
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = {name: (p, kind) for name, p, kind in helpers.small_cases()}
+TOL_U = 1e-5      # north_star: controls within 1e-5 relative of the reference CPU loop
+TOL_COST = 1e-9   # SURVEY.md 8c O->G
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(gpu_required):
+    capi.load()
+
+
+def start_state(p, path, lateral=0.0):
+    s = np.zeros(p.nstate)
+    s[0], s[1] = path[0][0], path[1][0] + lateral
+    return s
+
+
+# --------------------------------------------------------------------------------------------------------------
+# noise: GPU Philox + Box-Muller == CPU restatement, bit for bit
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model", ["diff_drive", "steering_diff_drive", "full_body"])
+def test_noise_bit_exact(model):
+    mk = {"diff_drive": configs.diff_drive_defaults, "steering_diff_drive": configs.steering_defaults,
+          "full_body": configs.full_body_defaults}[model]
+    K, H, off = 1000, 50, 123457
+    p = mk(K, H).with_(control_noise=1.0, u_min=tuple([-1e30] * configs.UDIM[model]),
+                       u_max=tuple([1e30] * configs.UDIM[model]))
+    g = MPPIController(p, sample_offset=off)
+    seed, it = 0x0123456789ABCDEF, (1 << 33) + 5
+    g.sampling(seed, it)
+    got = g.read_controls()
+    o = helpers.oracle_for(p)
+    o.sampling(seed, rng="philox", iteration=it, k_offset=off)
+    np.testing.assert_array_equal(got, o.get_controls())
+    z = got.ravel()
+    assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.02
+
+
+def test_sampling_uses_nominal_sigma_and_clamp():
+    p = configs.workload("C3").params.with_(num_samples=513, horizon=20)
+    g, o = MPPIController(p), helpers.oracle_for(p)
+    nominal = np.random.default_rng(0).normal(0, 0.4, size=(p.horizon - 1, p.udim))
+    g.set_nominal(nominal)
+    o.set_nominal(nominal)
+    np.testing.assert_array_equal(g.get_nominal(), nominal)
+    g.sampling(5, 9)
+    o.sampling(5, rng="philox", iteration=9)
+    u = g.read_controls()
+    np.testing.assert_array_equal(u, o.get_controls())
+    for d in range(p.udim):
+        assert u[..., d].min() >= p.u_min[d] and u[..., d].max() <= p.u_max[d]
+        assert (u[..., d] == p.u_max[d]).any() or (u[..., d] == p.u_min[d]).any()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# O->G: injected reference-generator samples, every small case, three consecutive closed-loop iterations
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_injected_controls_match_oracle(name):
+    p, kind = CASES[name]
+    path = helpers.oracle_path(kind)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    state = start_state(p, path)
+    for it in range(3):
+        xr, yr, yaw = helpers.oracle_window(p, path, state)
+        u_in = o.get_nominal()
+        g.set_nominal(u_in)
+        # reference call order (dd:352-358)
+        o.sampling(1000 + it, rng="mt19937")
+        g.inject_controls(o.get_controls())
+        o.predict_States(state, p.dt)
+        g.predict_States(state, p.dt)
+        o.calc_Weights(xr, yr, yaw[0])
+        g.calc_Weights(xr, yr, yaw[0])
+        u_o = o.determine_OptimalSolution()
+        u_g, st = g.determine_OptimalSolution(want_stats=True)
+
+        xy = g.read_candidates()
+        np.testing.assert_allclose(xy[..., 0], o.states("x"), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(xy[..., 1], o.states("y"), rtol=1e-12, atol=1e-13)
+        c_o, c_g = o.costs(), g.read_costs()
+        assert np.max(np.abs(c_g - c_o) / np.abs(c_o)) < TOL_COST
+        assert abs(st.sum_w - o.sum_w()) <= 1e-9 * o.sum_w()
+        np.testing.assert_allclose(g.read_weights(), o.weights(), rtol=1e-8, atol=1e-300)
+        assert st.min_cost == c_g.min() and st.max_cost == c_g.max()
+        assert st.n_zero_weight == int((np.exp(-c_g / p.lam) == 0).sum()) and st.nonfinite == 0
+        assert helpers.rel_err(u_g, u_o) < TOL_U
+        assert helpers.rel_err(u_g, u_o) < 1e-9          # what the fp64 path actually delivers
+        np.testing.assert_array_equal(g.get_nominal(), u_g)
+        state = helpers.plant(p.model, state, u_o[0], p.dt)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_vectors_through_the_gpu(name):
+    """The committed fixtures (inputs + expected outputs) replayed through the HIP path."""
+    p, kind = CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    sel = [0, 1, p.num_samples - 1]
+    for it in range(3):
+        pre = "it%d_" % it
+        o.set_nominal(gold[pre + "u_in"])
+        o.sampling(int(gold[pre + "seed"]), rng="mt19937")
+        ctrl = o.get_controls()
+        np.testing.assert_allclose(ctrl[sel], gold[pre + "controls_sel"], rtol=1e-14, atol=1e-16)
+        g.set_nominal(gold[pre + "u_in"])
+        g.inject_controls(ctrl)
+        g.predict_States(gold[pre + "x0"], p.dt)
+        g.calc_Weights(gold[pre + "x_ref"], gold[pre + "y_ref"], float(gold[pre + "yaw_ref0"]))
+        u_g, st = g.determine_OptimalSolution(want_stats=True)
+        assert np.max(np.abs(g.read_costs() - gold[pre + "costs"]) / gold[pre + "costs"]) < TOL_COST
+        assert abs(st.sum_w - gold[pre + "sum_w"]) <= 1e-9 * gold[pre + "sum_w"]
+        assert helpers.rel_err(u_g, gold[pre + "u_out"]) < 1e-9
+        xy = g.read_candidates()[sel]
+        np.testing.assert_allclose(xy[..., 0], gold[pre + "x_sel"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(xy[..., 1], gold[pre + "y_sel"], rtol=1e-12, atol=1e-13)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# R'->G: the fused production iteration (device Philox) against the oracle's philox mode
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_fused_iteration_matches_oracle_philox(name):
+    p, kind = CASES[name]
+    path = helpers.oracle_path(kind)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    state = start_state(p, path, lateral=0.07)
+    for it in range(4):
+        xr, yr, yaw = helpers.oracle_window(p, path, state)
+        u_o = o.iterate(state, p.dt, xr, yr, yaw[0], seed=77, rng="philox", iteration=it)
+        u_g, st = g.iterate(state, p.dt, xr, yr, yaw[0], 77, it)
+        np.testing.assert_array_equal(g.read_controls(), o.get_controls())
+        assert np.max(np.abs(g.read_costs() - o.costs()) / o.costs()) < TOL_COST
+        assert helpers.rel_err(u_g, u_o) < 1e-8
+        # keep the two loops on the same nominal so the next iteration's noise means are bit-identical
+        o.set_nominal(u_g)
+        state = helpers.plant(p.model, state, u_g[0], p.dt)
+
+
+@pytest.mark.parametrize("name", ["dd_K256_H50_sinusoid_C2", "sd_K256_H50_sinusoid_C3", "fb_K128_H80_dkan_C4"])
+def test_fused_equals_stagewise_bitwise(name):
+    p, kind = CASES[name]
+    path = helpers.oracle_path(kind)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    a, b = MPPIController(p), MPPIController(p)
+    u_a, st_a = a.iterate(state, p.dt, xr, yr, yaw[0], 3, 0)
+    b.sampling(3, 0)
+    b.predict_States(state, p.dt)
+    b.calc_Weights(xr, yr, yaw[0])
+    u_b, st_b = b.determine_OptimalSolution(want_stats=True)
+    np.testing.assert_array_equal(a.read_controls(), b.read_controls())
+    np.testing.assert_array_equal(a.read_candidates(), b.read_candidates())
+    np.testing.assert_array_equal(a.read_costs(), b.read_costs())
+    np.testing.assert_array_equal(u_a, u_b)
+    assert st_a.sum_w == st_b.sum_w
+
+
+def test_scalar_window_variant_matches_lds_variant(monkeypatch):
+    p, kind = CASES["dd_K256_H50_sinusoid_C2"]
+    path = helpers.oracle_path(kind)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    a = MPPIController(p)
+    monkeypatch.setenv("CCV_MPPI_WINDOW", "scalar")
+    b = MPPIController(p)
+    u_a = a.iterate(state, p.dt, xr, yr, yaw[0], 3, 0, want_stats=False)
+    u_b = b.iterate(state, p.dt, xr, yr, yaw[0], 3, 0, want_stats=False)
+    np.testing.assert_array_equal(a.read_costs(), b.read_costs())
+    np.testing.assert_array_equal(u_a, u_b)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# edge cases
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [1, 2, 63, 64, 65, 255, 257, 2047, 2049, 4097])
+def test_ragged_sample_counts(K):
+    p = configs.workload("C2").params.with_(num_samples=K, horizon=17)
+    path = helpers.oracle_path("sinusoid")
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    u_o = o.iterate(state, p.dt, xr, yr, yaw[0], seed=1, rng="philox", iteration=0)
+    u_g, st = g.iterate(state, p.dt, xr, yr, yaw[0], 1, 0)
+    assert np.max(np.abs(g.read_costs() - o.costs()) / o.costs()) < TOL_COST
+    assert helpers.rel_err(u_g, u_o) < 1e-9
+    assert abs(st.sum_w - o.sum_w()) <= 1e-9 * o.sum_w()
+
+
+@pytest.mark.parametrize("model,H", [("diff_drive", 3), ("diff_drive", 4), ("diff_drive", 9), ("diff_drive", 128),
+                                     ("steering_diff_drive", 3), ("steering_diff_drive", 127), ("full_body", 3),
+                                     ("full_body", 4), ("full_body", 10), ("full_body", 128)])
+def test_horizon_extremes(model, H):
+    mk = {"diff_drive": configs.diff_drive_defaults, "steering_diff_drive": configs.steering_defaults,
+          "full_body": configs.full_body_defaults}[model]
+    p = mk(96, H)
+    path = helpers.oracle_path("dkan")
+    state = start_state(p, path, lateral=-0.1)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    u_o = o.iterate(state, p.dt, xr, yr, yaw[0], seed=2, rng="philox", iteration=1)
+    u_g, st = g.iterate(state, p.dt, xr, yr, yaw[0], 2, 1)
+    c_o = o.costs()
+    assert np.max(np.abs(g.read_costs() - c_o) / np.maximum(np.abs(c_o), 1e-300)) < TOL_COST
+    assert helpers.rel_err(u_g, u_o) < 1e-9
+
+
+def test_all_weights_underflow_gives_nan_like_the_reference():
+    """dd:219-222 has no min-cost shift: when every exp underflows the update is 0/0."""
+    p = configs.workload("C2").params.with_(num_samples=128, horizon=20, path_weight=1e4)
+    path = helpers.oracle_path("sinusoid")
+    state = np.array([3.0, 40.0, 0.0])    # far from the path: cost >> 745
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    u_o = o.iterate(state, p.dt, xr, yr, yaw[0], seed=1, rng="philox", iteration=0)
+    u_g, st = g.iterate(state, p.dt, xr, yr, yaw[0], 1, 0)
+    assert o.sum_w() == 0.0 and np.all(np.isnan(u_o))
+    assert st.sum_w == 0.0 and np.all(np.isnan(u_g)) and st.nonfinite == 1 and st.n_zero_weight == 128
+    # the flagged, non-reference min-shift mode stays finite and equals the shifted softmax of the same costs
+    g2 = MPPIController(p, min_shift=True)
+    u2, st2 = g2.iterate(state, p.dt, xr, yr, yaw[0], 1, 0)
+    c, u = o.costs(), o.get_controls()
+    w = np.exp(-(c - c.min()) / p.lam)
+    assert st2.nonfinite == 0
+    np.testing.assert_allclose(u2, np.einsum("i,itd->td", w / w.sum(), u), rtol=1e-9, atol=1e-12)
+
+
+def test_distance_gate_100m():
+    """calc_MinDistance starts from min_distance = 100 (dd:185): farther points all cost path_weight*100^2."""
+    p = configs.diff_drive_defaults(64, 10)
+    path = helpers.oracle_path("straight")
+    state = np.array([5000.0, 5000.0, 0.3])
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    o.iterate(state, p.dt, xr, yr, yaw[0], seed=1, rng="philox", iteration=0)
+    g.iterate(state, p.dt, xr, yr, yaw[0], 1, 0)
+    assert np.all(o.costs() >= p.horizon * p.path_weight * 1e4)
+    np.testing.assert_allclose(g.read_costs(), o.costs(), rtol=1e-12)
+
+
+def test_large_world_coordinates():
+    """Window coefficients are taken relative to the current pose, so an odom origin far away costs no accuracy."""
+    p = configs.workload("C2").params.with_(num_samples=128, horizon=30)
+    px, py = helpers.oracle_path("sinusoid")
+    off = np.array([12345.678, -9876.543])
+    path = (px + off[0], py + off[1])
+    state = np.array([off[0] + 0.2, off[1] - 0.1, 0.1])
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    u_o = o.iterate(state, p.dt, xr, yr, yaw[0], seed=4, rng="philox", iteration=0)
+    u_g = g.iterate(state, p.dt, xr, yr, yaw[0], 4, 0, want_stats=False)
+    assert np.max(np.abs(g.read_costs() - o.costs()) / o.costs()) < TOL_COST
+    assert helpers.rel_err(u_g, u_o) < 1e-8
+
+
+def test_read_back_ranges_and_errors():
+    p = configs.workload("C2").params.with_(num_samples=300, horizon=12)
+    path = helpers.oracle_path("sinusoid")
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    g = MPPIController(p)
+    with pytest.raises(MPPIError) as e:
+        g.predict_States(state, p.dt)          # rollout before sampling
+    assert e.value.code == capi.ERR_STATE
+    with pytest.raises(MPPIError):
+        g.read_costs()
+    g.iterate(state, p.dt, xr, yr, yaw[0], 1, 0)
+    full = g.read_candidates()
+    assert full.shape == (300, 12, 2)
+    np.testing.assert_array_equal(g.read_candidates(5, 30, 7), full[5:5 + 30 * 7:7])
+    np.testing.assert_array_equal(full[:, 0, 0], np.full(300, state[0]))
+    np.testing.assert_array_equal(g.read_costs(10, 20), g.read_costs()[10:30])
+    np.testing.assert_array_equal(g.read_controls(290, 10), g.read_controls()[290:])
+    assert abs(g.read_weights().sum() - 1.0) < 1e-12
+    for bad in (lambda: g.read_candidates(0, 301, 1), lambda: g.read_candidates(299, 2, 1), lambda: g.read_costs(290, 11),
+                lambda: g.read_candidates(0, 1, 0), lambda: g.read_controls(-1, 1)):
+        with pytest.raises(MPPIError) as e:
+            bad()
+        assert e.value.code == capi.ERR_INVALID_ARG
+    lean = MPPIController(p, no_state_store=True)
+    lean.iterate(state, p.dt, xr, yr, yaw[0], 1, 0)
+    np.testing.assert_array_equal(lean.read_costs(), g.read_costs())
+    with pytest.raises(MPPIError):
+        lean.read_candidates()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# full BASELINE sizes: size-independent properties
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wl", ["C2", "C3", "C4"])
+def test_full_size_properties(wl):
+    w = configs.workload(wl)
+    p = w.params
+    path = helpers.oracle_path(w.path)
+    state = start_state(p, path, lateral=0.05)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    g = MPPIController(p)
+    nominal = np.random.default_rng(1).normal(0, 0.2, size=(p.horizon - 1, p.udim))
+    g.set_nominal(nominal)
+    u1, st = g.iterate(state, p.dt, xr, yr, yaw[0], 42, 7)
+    K = p.num_samples
+    # (a) contiguous blocks of samples re-scored by the oracle (global sample ids via k_offset)
+    for first in (0, K // 2 - 100, K - 192):
+        o = helpers.oracle_for(p, 192)
+        o.set_nominal(nominal)
+        o.iterate(state, p.dt, xr, yr, yaw[0], seed=42, rng="philox", iteration=7, k_offset=first)
+        np.testing.assert_array_equal(g.read_controls(first, 192), o.get_controls())
+        c_o = o.costs()
+        assert np.max(np.abs(g.read_costs(first, 192) - c_o) / c_o) < TOL_COST
+        xy = g.read_candidates(first, 192, 1)
+        np.testing.assert_allclose(xy[..., 0], o.states("x"), rtol=1e-12, atol=1e-12)
+    # (b) the reduction at full size: weighted mean recomputed on the host from the device's own costs/controls
+    c = g.read_costs()
+    wts = np.exp(-c / p.lam)
+    assert abs(st.sum_w - wts.sum()) <= 1e-10 * wts.sum()
+    assert st.min_cost == c.min() and st.max_cost == c.max() and st.n_zero_weight == int((wts == 0).sum())
+    top = np.argsort(c)[:64]              # MPPI weights are extremely peaked (effective sample size O(1..10))
+    ctrl_top = np.stack([g.read_controls(int(i), 1)[0] for i in top])
+    u_host = np.einsum("i,itd->td", wts[top] / wts.sum(), ctrl_top)
+    resid = 1.0 - wts[top].sum() / wts.sum()        # weight mass not included above
+    umax = max(np.max(np.abs(p.u_min)), np.max(np.abs(p.u_max)))
+    assert np.max(np.abs(u_host - u1)) <= resid * umax + 1e-9
+    assert abs(g.read_weights().sum() - 1.0) < 1e-10
+    # (c) determinism: same inputs, same bits
+    g.set_nominal(nominal)
+    u2, st2 = g.iterate(state, p.dt, xr, yr, yaw[0], 42, 7)
+    np.testing.assert_array_equal(u1, u2)
+    assert st.sum_w == st2.sum_w
+    # (d) a different seed or iteration changes the draw
+    g.set_nominal(nominal)
+    u3 = g.iterate(state, p.dt, xr, yr, yaw[0], 42, 8, want_stats=False)
+    assert not np.array_equal(u1, u3)
+
+
+@pytest.mark.parametrize("wl,K", [("C2", 65536), ("C4", 8192)])
+def test_shard_invariance_via_partials(wl, K):
+    """K split over two handles with global sample ids: summed partials == the single-handle result."""
+    import torch
+    w = configs.workload(wl, num_samples=K)
+    p = w.params
+    path = helpers.oracle_path(w.path)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    whole = MPPIController(p)
+    u_whole, st = whole.iterate(state, p.dt, xr, yr, yaw[0], 9, 3)
+    cut = K // 2 + 64
+    a, b = MPPIController(p, num_samples=cut), MPPIController(p, num_samples=K - cut, sample_offset=cut)
+    n = a.partials_size()
+    assert n == 1 + (p.horizon - 1) * p.udim
+    pa = torch.zeros(n, dtype=torch.float64, device="cuda")
+    pb = torch.zeros(n, dtype=torch.float64, device="cuda")
+    a.iterate_partials_enqueue(state, p.dt, xr, yr, yaw[0], 9, 3, pa.data_ptr())
+    b.iterate_partials_enqueue(state, p.dt, xr, yr, yaw[0], 9, 3, pb.data_ptr())
+    a.synchronize()
+    b.synchronize()
+    np.testing.assert_array_equal(np.concatenate([a.read_costs(), b.read_costs()]), whole.read_costs())
+    tot = pa + pb
+    assert abs(tot[0].item() - st.sum_w) <= 1e-12 * st.sum_w
+    torch.cuda.synchronize()
+    a.apply_partials_enqueue(tot.data_ptr())
+    b.apply_partials_enqueue(tot.data_ptr())
+    np.testing.assert_allclose(a.get_nominal(), u_whole, rtol=1e-11, atol=1e-14)
+    np.testing.assert_array_equal(a.get_nominal(), b.get_nominal())
+
+
+def test_closed_loop_tracks_the_sinusoid():
+    """Behavioural check in the spirit of calc_e_rmse.py:30-49: the GPU controller follows the launch path."""
+    w = configs.workload("C2", num_samples=8192)
+    p = w.params
+    px, py = amd.make_path(w.path)
+    state = np.array([px[0], py[0], 0.0])
+    g = MPPIController(p)
+    errs = []
+    for it in range(60):
+        _, xr, yr, yaw = amd.calc_ref_path(px, py, state[0], state[1], p.v_ref, p.dt, p.resolution, p.horizon)
+        u = g.iterate(state, p.dt, xr, yr, yaw[0], 123, it, want_stats=False)
+        assert np.all(np.isfinite(u))
+        state = amd.plant_step(p.model, state, u[0], p.dt)
+        errs.append(np.min(np.hypot(px - state[0], py - state[1])))
+    assert state[0] > 3.0                      # made progress along x
+    assert np.sqrt(np.mean(np.square(errs[10:]))) < 0.25

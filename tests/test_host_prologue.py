@@ -1,0 +1,48 @@
+"""Host prologue of the product (libccv_mppi_hip.so: window builder, path generators, plant) against the
+oracle's restatement of the reference -- bit-exact, CPU only."""
+import numpy as np
+import pytest
+
+import helpers
+import ccv_mppi_path_tracker_amd as amd
+from oracle import oracle_lib as O
+
+
+@pytest.mark.parametrize("kind", ["straight", "sinusoid", "dkan"])
+def test_path_generators_bit_exact(kind):
+    px, py = amd.make_path(kind)
+    ox, oy = helpers.oracle_path(kind)
+    np.testing.assert_array_equal(px, ox)
+    np.testing.assert_array_equal(py, oy)
+
+
+@pytest.mark.parametrize("kind,v_ref,H", [("straight", 0.8, 15), ("sinusoid", 1.2, 50), ("dkan", 2.0, 80),
+                                          ("sinusoid", 0.8, 30), ("dkan", 1.2, 128)])
+def test_ref_window_bit_exact(kind, v_ref, H):
+    px, py = amd.make_path(kind)
+    rng = np.random.default_rng(1)
+    poses = [(px[0], py[0]), (px[-1], py[-1]), (1e3, -1e3), (px[40] + 0.3, py[40] - 0.2)]
+    poses += [(px[i] + dx, py[i] + dy) for i, dx, dy in zip(rng.integers(0, len(px), 40), rng.normal(0, 0.5, 40),
+                                                          rng.normal(0, 0.5, 40))]
+    for dt in (0.1, 0.093, 0.21):
+        for x, y in poses:
+            i1, xr1, yr1, yaw1 = amd.calc_ref_path(px, py, x, y, v_ref, dt, 0.1, H)
+            i2, xr2, yr2, yaw2 = O.calc_ref_path(px, py, x, y, v_ref, dt, 0.1, H)
+            assert i1 == i2
+            np.testing.assert_array_equal(xr1, xr2)
+            np.testing.assert_array_equal(yr1, yr2)
+            np.testing.assert_array_equal(yaw1[:H - 1], yaw2[:H - 1])
+
+
+def test_ref_window_rejects_bad_arguments():
+    px, py = amd.make_path("straight")
+    with pytest.raises(amd.controller.MPPIError):
+        amd.calc_ref_path(px[:0], py[:0], 0.0, 0.0, 1.0, 0.1, 0.1, 10)
+
+
+@pytest.mark.parametrize("model,n", [("diff_drive", 3), ("steering_diff_drive", 3), ("full_body", 5)])
+def test_plant_step_matches_predict_next_state(model, n):
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        s, u = rng.normal(size=n), rng.normal(size=5)
+        np.testing.assert_array_equal(amd.plant_step(model, s, u, 0.1), helpers.plant(model, s, u, 0.1))
