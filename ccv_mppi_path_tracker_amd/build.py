@@ -39,12 +39,13 @@ def stale():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source for gfx950 into LIB; returns the path."""
-    if not force and not stale():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """Compile every HIP source for gfx950 into LIB (or `out` for experiment builds); returns the path."""
+    if out is None and not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    target = out or LIB
+    cmd = [hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-o", target] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -52,7 +53,7 @@ def build(force=False, verbose=False, extra_flags=()):
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
     if verbose and res.stderr:
         print(res.stderr)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

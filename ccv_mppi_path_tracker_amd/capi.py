@@ -93,7 +93,7 @@ def load():
     """dlopen the in-tree library (building it first if it is missing or stale)."""
     global _lib
     if _lib is None:
-        path = _build.build()
+        path = os.environ.get("CCV_MPPI_LIB") or _build.build()   # CCV_MPPI_LIB: experiment builds only
         if not os.path.exists(path):
             raise ImportError("libccv_mppi_hip.so is missing and could not be built; there is no CPU fallback")
         lib = C.CDLL(path)

@@ -140,10 +140,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, co
             px[tt] = x - A.x0[0];
             py[tt] = y - A.x0[1];
             if (t < H) {
+#if !defined(CCV_ABL_NO_STORE)
                 if (A.store_xy && live) {
                     A.xs[(size_t)t * pitch + k] = x;
                     A.ys[(size_t)t * pitch + k] = y;
                 }
+#endif
                 if (t < H - 1) {
                     double u[UD];
                     static_for<UD>([&](auto D) {
@@ -152,10 +154,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, co
                         const size_t row = (size_t)(t * UD + d);
                         if constexpr (SRC == SRC_PHILOX) {
                             if constexpr ((nloc & 3) == 0) {
+#if defined(CCV_ABL_NO_NOISE)
+                                zq[0] = zq[1] = zq[2] = zq[3] = (float)kg * 1e-6f;
+#else
                                 const Philox4 r = philox4x32_10(kg, (uint32_t)((t0 * UD + nloc) >> 2), A.iter_lo,
                                                                 A.iter_hi, A.seed_lo, A.seed_hi);
+#if defined(CCV_ABL_NO_BM)
+                                zq[0] = (float)r.x * 1e-10f; zq[1] = (float)r.y * 1e-10f;
+                                zq[2] = (float)r.z * 1e-10f; zq[3] = (float)r.w * 1e-10f;
+#else
                                 box_muller_f32(r.x, r.y, zq[0], zq[1]);
                                 box_muller_f32(r.z, r.w, zq[2], zq[3]);
+#endif
+#endif
                             }
                             // libstdc++ normal_distribution: ret * stddev + mean (dd:96-97), then clamp (dd:98-99)
                             double v = (double)zq[nloc & 3] * A.sigma + A.nominal[row];
@@ -164,7 +175,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, co
                                 if (A.steer_off) v = 0.0;  // fb:517
                             }
                             u[d] = v;
+#if !defined(CCV_ABL_NO_STORE)
                             if (A.store_u && live) A.u[row * pitch + k] = v;
+#endif
                         } else {
                             u[d] = A.u[row * pitch + kk];
                         }
@@ -193,7 +206,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, co
                     double hd = yaw;
                     if constexpr (MODEL != CCV_MPPI_DIFF_DRIVE) hd = yaw + u[2];
                     double sn, cs;
+#if defined(CCV_ABL_NO_SINCOS)
+                    sn = hd * 0.5; cs = 1.0 - hd * 0.25;
+#else
                     sincos(hd, &sn, &cs);
+#endif
                     if constexpr (MODEL == CCV_MPPI_FULL_BODY) {
                         if (A.do_cost) {
                             double sd_, cd_, sr_, cr_;
@@ -227,7 +244,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, co
         if (A.do_cost) {
             // states that reach the path cost: all H for dd/sd (dd:199), the first H-2 for fb (fb:409)
             const int nstates = (MODEL == CCV_MPPI_FULL_BODY) ? H - 2 : H;
+#if defined(CCV_ABL_NO_DIST)
+            const int nv = 0;
+#else
             const int nv = min(kTU, nstates - t0);
+#endif
             if (nv > 0) {
                 double m[kTU];
 #pragma unroll

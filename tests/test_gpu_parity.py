@@ -385,19 +385,25 @@ def test_shard_invariance_via_partials(wl, K):
     np.testing.assert_array_equal(a.get_nominal(), b.get_nominal())
 
 
-def test_closed_loop_tracks_the_sinusoid():
-    """Behavioural check in the spirit of calc_e_rmse.py:30-49: the GPU controller follows the launch path."""
-    w = configs.workload("C2", num_samples=8192)
+def test_closed_loop_matches_oracle_and_tracks():
+    """Closed loop in the spirit of record_state.py / calc_e_rmse.py:30-49: the GPU controller and the oracle
+    (philox mode) drive the same kinematic plant along the launch sinusoid and must stay together."""
+    w = configs.workload("C2", num_samples=2048)
     p = w.params
     px, py = amd.make_path(w.path)
-    state = np.array([px[0], py[0], 0.0])
-    g = MPPIController(p)
+    s_g = np.array([px[0], py[0], 0.0])
+    s_o = s_g.copy()
+    g, o = MPPIController(p), helpers.oracle_for(p)
     errs = []
     for it in range(60):
-        _, xr, yr, yaw = amd.calc_ref_path(px, py, state[0], state[1], p.v_ref, p.dt, p.resolution, p.horizon)
-        u = g.iterate(state, p.dt, xr, yr, yaw[0], 123, it, want_stats=False)
-        assert np.all(np.isfinite(u))
-        state = amd.plant_step(p.model, state, u[0], p.dt)
-        errs.append(np.min(np.hypot(px - state[0], py - state[1])))
-    assert state[0] > 3.0                      # made progress along x
-    assert np.sqrt(np.mean(np.square(errs[10:]))) < 0.25
+        _, xr, yr, yaw = amd.calc_ref_path(px, py, s_g[0], s_g[1], p.v_ref, p.dt, p.resolution, p.horizon)
+        u_g = g.iterate(s_g, p.dt, xr, yr, yaw[0], 123, it, want_stats=False)
+        xr_o, yr_o, yaw_o = helpers.oracle_window(p, (px, py), s_o)
+        u_o = o.iterate(s_o, p.dt, xr_o, yr_o, yaw_o[0], seed=123, rng="philox", iteration=it)
+        assert np.all(np.isfinite(u_g))
+        s_g = amd.plant_step(p.model, s_g, u_g[0], p.dt)
+        s_o = helpers.plant(p.model, s_o, u_o[0], p.dt)
+        errs.append(np.min(np.hypot(px - s_g[0], py - s_g[1])))
+    assert np.max(np.abs(s_g - s_o)) < 1e-6     # 60 feedback steps apart by rounding only
+    assert s_g[0] > 1.5                        # made progress along the path
+    assert np.sqrt(np.mean(np.square(errs[10:]))) < 0.5
