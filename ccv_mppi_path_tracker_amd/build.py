@@ -12,7 +12,7 @@ CSRC = os.path.join(_PKG, "csrc")
 LIBDIR = os.path.join(_PKG, "lib")
 LIB = os.path.join(LIBDIR, "libccv_mppi_hip.so")
 SOURCES = ["ccv_mppi_capi.hip", "ccv_mppi_host.cpp"]
-DEPS = ["ccv_mppi_capi.hip", "ccv_mppi_host.cpp", "mppi_kernels.h", "noise_spec.h",
+DEPS = ["ccv_mppi_capi.hip", "ccv_mppi_host.cpp", "mppi_kernels.h", "mppi_rollout_pc.h", "fast_trig.h", "noise_spec.h",
         os.path.join("..", "..", "include", "ccv_mppi.h"), os.path.join("..", "..", "include", "ccv_mppi_host.h")]
 
 HIPCC_FLAGS = [

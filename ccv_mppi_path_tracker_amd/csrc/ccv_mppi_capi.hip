@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "mppi_kernels.h"
+#include "mppi_rollout_pc.h"
 
 using namespace ccv;
 
@@ -31,6 +32,7 @@ struct ccv_mppi_handle {
     double* d_vec = nullptr;
     double* d_stats = nullptr;
     double* d_cmin = nullptr;
+    unsigned long long* d_dbg = nullptr;   // CCV_STAMP diagnostic builds
     double* d_scratch = nullptr;  // read-back staging
     size_t scratch_bytes = 0;
     // pinned host staging
@@ -40,8 +42,10 @@ struct ccv_mppi_handle {
     bool have_controls = false, have_rollout = false, have_weights = false;
     double st_x0[5] = {0, 0, 0, 0, 0};
     double st_dt = 0.1;
-    // window of the last cost evaluation
+    // kernel selection (experiments): CCV_MPPI_KERNEL=v1 -> one-sample-per-lane k_rollout_cost,
+    // CCV_MPPI_WINDOW=scalar -> its scalar-load window variant; default = k_rollout_pc
     int lds_window = 1;
+    int coop = 1;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // triples: start, after rollout, end
@@ -129,6 +133,7 @@ void fill_args(const ccv_mppi_handle* h, RolloutArgs& A, const double* x0, doubl
     A.ys = h->d_ys;
     A.cost = h->d_cost;
     A.w = h->d_w;
+    A.dbg = h->d_dbg;
 }
 
 // Window coefficients relative to the current pose: |p - r_j|^2 = |p|^2 + a_j px + b_j py + c_j
@@ -141,10 +146,19 @@ void fill_window(const ccv_mppi_handle* h, Window& W, const double* x0, const do
     }
 }
 
+// mode: MODE_FUSED / MODE_ROLLOUT / MODE_COST (mppi_rollout_coop.h)
 template <int MODEL>
-void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int src) {
+void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int mode) {
+    if (h->coop) {
+        const dim3 cgrid((h->K + kPcSamples - 1) / kPcSamples), cblock(kPcWaves * 64);
+        if (mode == MODE_FUSED) hipLaunchKernelGGL((k_rollout_pc<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, A, W);
+        else if (mode == MODE_ROLLOUT) hipLaunchKernelGGL((k_rollout_pc<MODEL, MODE_ROLLOUT>), cgrid, cblock, 0, h->stream, A, W);
+        else hipLaunchKernelGGL((k_rollout_pc<MODEL, MODE_COST>), cgrid, cblock, 0, h->stream, A, W);
+        return;
+    }
+    // experiment path (CCV_MPPI_KERNEL=v1): plain one-sample-per-lane kernel
     const dim3 grid((h->K + kBlock - 1) / kBlock), block(kBlock);
-    if (src == SRC_PHILOX) {
+    if (mode == MODE_FUSED) {
         if (h->lds_window) hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_PHILOX, true>), grid, block, 0, h->stream, A, W);
         else hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_PHILOX, false>), grid, block, 0, h->stream, A, W);
     } else {
@@ -153,11 +167,11 @@ void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const 
     }
 }
 
-int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int src) {
+int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int mode) {
     switch (h->cfg.model) {
-        case CCV_MPPI_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_DIFF_DRIVE>(h, A, W, src); break;
-        case CCV_MPPI_STEERING_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_STEERING_DIFF_DRIVE>(h, A, W, src); break;
-        default: launch_rollout_model<CCV_MPPI_FULL_BODY>(h, A, W, src); break;
+        case CCV_MPPI_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_DIFF_DRIVE>(h, A, W, mode); break;
+        case CCV_MPPI_STEERING_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_STEERING_DIFF_DRIVE>(h, A, W, mode); break;
+        default: launch_rollout_model<CCV_MPPI_FULL_BODY>(h, A, W, mode); break;
     }
     HIP_TRY(h, hipGetLastError());
     return CCV_MPPI_OK;
@@ -201,7 +215,7 @@ int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out) {
     F.R = h->R;
     F.nchunks = h->nchunks;
     F.normalise = normalise ? 1 : 0;
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, h->stream, F);
+    hipLaunchKernelGGL(k_finalize, dim3((h->R + 3) / 4), dim3(kBlock), 0, h->stream, F);
     HIP_TRY(h, hipGetLastError());
     return CCV_MPPI_OK;
 }
@@ -259,7 +273,7 @@ int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const dou
         int rc = timing_begin(h, slot);
         if (rc) return rc;
     }
-    int rc = launch_rollout(h, A, W, SRC_PHILOX);
+    int rc = launch_rollout(h, A, W, MODE_FUSED);
     if (rc) return rc;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[slot + 1], h->stream));
     rc = launch_update(h, normalise, vec_out);
@@ -333,6 +347,8 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     h->nchunks = (h->K + kChunk - 1) / kChunk;
     const char* env = getenv("CCV_MPPI_WINDOW");
     h->lds_window = !(env && std::strcmp(env, "scalar") == 0);
+    const char* kenv = getenv("CCV_MPPI_KERNEL");
+    h->coop = !(kenv && std::strcmp(kenv, "v1") == 0) && h->lds_window;
 
     auto bail = [&](int code, const char* what, hipError_t e) {
         fail(h, code, what, e);
@@ -346,7 +362,7 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     h->stream = h->own_stream;
     const size_t P = (size_t)h->pitch;
     struct { double** p; size_t n; } allocs[] = {
-        {&h->d_nominal, (size_t)h->R},
+        {&h->d_nominal, (size_t)(CCV_MPPI_MAX_HORIZON + 8) * CCV_MPPI_MAX_UDIM},   // padded: read 4 at a time
         {&h->d_u, (size_t)h->R * P},
         {&h->d_xs, (size_t)h->H * P},
         {&h->d_ys, (size_t)h->H * P},
@@ -362,6 +378,9 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
         if ((e = hipMalloc(a.p, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
         if ((e = hipMemset(*a.p, 0, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipMemset", e);
     }
+#if defined(CCV_STAMP)
+    if ((e = hipMalloc(&h->d_dbg, (64 + 3 * 4096) * sizeof(unsigned long long))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
+#endif
     h->pin_doubles = (size_t)h->R + 16;
     if ((e = hipHostMalloc(&h->h_pin, h->pin_doubles * sizeof(double), hipHostMallocDefault)) != hipSuccess)
         return bail(CCV_MPPI_ERR_ALLOC, "hipHostMalloc", e);
@@ -390,6 +409,30 @@ int ccv_mppi_set_stream(ccv_mppi_handle* h, void* hip_stream) {
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return CCV_MPPI_OK;
 }
+
+#if defined(CCV_STAMP)
+extern "C" int ccv_mppi_debug_occupancy(int* out3) {
+    hipFuncAttributes fa;
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout_pc<CCV_MPPI_DIFF_DRIVE, MODE_FUSED>, kPcWaves * 64, 0);
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_rollout_pc<CCV_MPPI_DIFF_DRIVE, MODE_FUSED>));
+    out3[0] = nb;
+    out3[1] = fa.numRegs;
+    out3[2] = (int)fa.sharedSizeBytes;
+    out3[3] = (int)fa.localSizeBytes;
+    return 0;
+}
+extern "C" int ccv_mppi_debug_stamps(ccv_mppi_handle* h, unsigned long long* out32) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out32, h->d_dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return CCV_MPPI_OK;
+}
+extern "C" int ccv_mppi_debug_blocks(ccv_mppi_handle* h, unsigned long long* out, int nblocks) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, h->d_dbg + 64, (size_t)nblocks * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return CCV_MPPI_OK;
+}
+#endif
 
 int ccv_mppi_synchronize(ccv_mppi_handle* h) {
     if (!h) return CCV_MPPI_ERR_INVALID_ARG;
@@ -485,7 +528,7 @@ int ccv_mppi_rollout(ccv_mppi_handle* h, const double* x0, double dt) {
     A.store_u = 0;
     A.store_xy = 1;
     A.do_cost = 0;
-    int rc = launch_rollout(h, A, W, SRC_BUFFER);
+    int rc = launch_rollout(h, A, W, MODE_ROLLOUT);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(h->st_x0, A.x0, sizeof(h->st_x0));
@@ -506,7 +549,7 @@ int ccv_mppi_weights(ccv_mppi_handle* h, const double* x_ref, const double* y_re
     A.store_xy = 0;
     A.do_cost = 1;
     // the rollout is recomputed from the stored controls (bit-identical to the stored states) and scored
-    int rc = launch_rollout(h, A, W, SRC_BUFFER);
+    int rc = launch_rollout(h, A, W, MODE_COST);
     if (rc) return rc;
     // sum of weights (calc_Weights normalises, dd:222) without touching u*
     rc = launch_update(h, false, nullptr);

@@ -1,0 +1,48 @@
+// Branch-free fp64 sin/cos for the rollout (predict_NextState, dd:106-107).
+//
+// OCML's sincos() carries a large-argument (Payne-Hanek) branch, which splits the unrolled time block into basic blocks
+// and stops the scheduler from interleaving the eight independent heading evaluations of a block.  This version is
+// straight-line code: Cody-Waite reduction by pi/2 in three FMA steps (exact products for |n| < 2^20), then the fdlibm
+// kernel polynomials (Sun Microsystems' __kernel_sin/__kernel_cos minimax coefficients, |error| < 2^-58 on [-pi/4, pi/4]).
+// Valid for |x| <= kFastTrigLimit; callers test the whole wave with fast_trig_ok() and fall back to sincos() otherwise.
+// Max observed difference to the correctly rounded result: 1 ulp (tests/test_gpu_parity.py::test_fast_trig).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ccv {
+
+constexpr double kFastTrigLimit = 1.0e5;
+
+__device__ __forceinline__ bool fast_trig_ok(double x) { return fabs(x) <= kFastTrigLimit; }   // false for NaN/Inf
+
+__device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
+    const double fn = __builtin_rint(x * 6.36619772367581382433e-01);   // n = nearest integer to x * 2/pi
+    double r = fma(-fn, 1.57079632673412561417e+00, x);                  // pi/2, first 33 bits: exact product
+    r = fma(-fn, 6.07710050630396597660e-11, r);                         // next 33 bits
+    r = fma(-fn, 2.02226624879595063154e-21, r);                         // tail
+    const double z = r * r;
+    // sin(r) = r + r^3 * (S1 + z*(S2 + ... ))
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = fma(z * r, ps, r);
+    // cos(r) = 1 - z/2 + z^2 * (C1 + z*(C2 + ...)), summed as fdlibm does to keep the last bit
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+    // quadrant
+    const int q = (int)fn;
+    const double sa = (q & 1) ? cr : sr;
+    const double ca = (q & 1) ? sr : cr;
+    s = (q & 2) ? -sa : sa;
+    c = ((q + 1) & 2) ? -ca : ca;
+}
+
+}  // namespace ccv

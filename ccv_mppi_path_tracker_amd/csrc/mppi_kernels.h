@@ -54,12 +54,13 @@ struct RolloutArgs {
     uint32_t seed_lo, seed_hi, iter_lo, iter_hi;
     int32_t K, pitch, H, k_offset;
     int32_t steer_off, store_u, store_xy, do_cost;
-    const double* nominal;
+    const double* __restrict__ nominal;
     double* u;
     double* xs;
     double* ys;
     double* cost;
     double* w;
+    unsigned long long* dbg;   // diagnostic builds only (CCV_STAMP): per-phase cycle sums
 };
 
 template <int N, class F, int... I>
@@ -406,32 +407,42 @@ struct FinalizeArgs {
     int32_t R, nchunks, normalise;
 };
 
-// One block.  Thread n sums the chunk partials of row n in ascending chunk order; u*[n] = V_n / S
+// One wave per row n: lanes read the chunk partials of the row (fixed order => bitwise reproducible), wave-reduce them,
+// and re-derive S = sum w the same way, so no cross-block hand-off is needed.  u*[n] = V_n / S
 // (== sum_i (w_i/S) u_i of dd:222,234 up to rounding; S == 0 gives NaN exactly as dd:222 does).
 __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
-    __shared__ double s_sum;
-    if (threadIdx.x == 0) {
-        double s = 0.0, mn = INFINITY, mx = -INFINITY, nz = 0.0;
-        for (int c = 0; c < A.nchunks; ++c) {
-            s += A.partial[(size_t)A.R * A.nchunks + c];
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);   // row handled by this wave
+    double s = 0.0;
+    for (int c = lane; c < A.nchunks; c += 64) s += A.partial[(size_t)A.R * A.nchunks + c];
+    s = wave_sum(s);
+    s = __shfl(s, 0, 64);
+    if (n < A.R) {
+        double v = 0.0;
+        for (int c = lane; c < A.nchunks; c += 64) v += A.partial[(size_t)n * A.nchunks + c];
+        v = wave_sum(v);
+        if (lane == 0) {
+            A.vec[1 + n] = v;
+            if (A.normalise) A.nominal[n] = v / s;
+        }
+    }
+    if (n == 0) {
+        double mn = INFINITY, mx = -INFINITY, nz = 0.0;
+        for (int c = lane; c < A.nchunks; c += 64) {
             mn = fmin(mn, A.statpart[c * 3 + 0]);
             mx = fmax(mx, A.statpart[c * 3 + 1]);
             nz += A.statpart[c * 3 + 2];
         }
-        s_sum = s;
-        A.vec[0] = s;
-        A.stats[0] = s;
-        A.stats[1] = mn;
-        A.stats[2] = mx;
-        A.stats[3] = nz;
-    }
-    __syncthreads();
-    const double S = s_sum;
-    for (int n = threadIdx.x; n < A.R; n += kBlock) {
-        double v = 0.0;
-        for (int c = 0; c < A.nchunks; ++c) v += A.partial[(size_t)n * A.nchunks + c];
-        A.vec[1 + n] = v;
-        if (A.normalise) A.nominal[n] = v / S;
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        nz = wave_sum(nz);
+        if (lane == 0) {
+            A.vec[0] = s;
+            A.stats[0] = s;
+            A.stats[1] = mn;
+            A.stats[2] = mx;
+            A.stats[3] = nz;
+        }
     }
 }
 

@@ -1,0 +1,527 @@
+// k_rollout_pc: the production sample + rollout + cost kernel ("producer / consumer" time blocks).
+//
+// One sample per lane.  A workgroup is TWO waves that own the same 64 samples and alternate roles over time blocks
+// of kTU = 8 steps:
+//
+//   step s:   wave (s & 1)        PRODUCES block s   : Philox noise -> clamped controls -> HBM, Euler rollout with sincos,
+//                                                      x,y -> HBM, control / ZMP cost terms; hands (x,y) of its 8 states
+//                                                      and the end state to the other wave through LDS
+//             wave ((s - 1) & 1)  CONSUMES block s-1 : squared distance of its 8 states to every point of the reference
+//                                                      window (2 FMA + 1 MIN per pair, the O(K*H^2) core) -> path cost
+//             barrier
+//
+// Why: at K = 65 536 a plain one-sample-per-lane grid is exactly one wave per SIMD (1024 waves on 1024 SIMDs) and
+// every stall is exposed -- the wave that waits for a store slot, an LDS broadcast or a Philox multiply leaves its
+// SIMD idle (measured 75 us for one iteration vs 41 us per 65 536 samples once 8 waves share a SIMD).  Splitting the
+// sample's work by time block gives 2048 waves (2 per SIMD) with complementary instruction mixes (integer/trig/stores
+// vs straight fp64 FMA/MIN) and no duplicated arithmetic: per sample the operations are exactly those of
+// k_rollout_cost; only the order in which one sample's cost terms are added differs.
+#pragma once
+#include "fast_trig.h"
+#include "mppi_kernels.h"
+
+namespace ccv {
+
+constexpr int kPcWaves = 2;
+constexpr int kPcSamples = 64;
+
+enum : int { MODE_FUSED = 0, MODE_ROLLOUT = 1, MODE_COST = 2 };
+//   MODE_FUSED    device Philox noise, controls + states stored, cost + weight   (ccv_mppi_iterate*)
+//   MODE_ROLLOUT  controls read from HBM, states stored, no cost                  (ccv_mppi_rollout)
+//   MODE_COST     controls read from HBM, nothing stored but cost + weight        (ccv_mppi_weights)
+
+#if defined(CCV_STAMP)
+struct PcStamps { unsigned long long acc[8]; unsigned long long last; };
+#define CCV_STAMP_AT(st, slot)                                                              \
+    do {                                                                                     \
+        unsigned long long now__;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now__)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        (st).acc[slot] += now__ - (st).last;                                                 \
+        (st).last = now__;                                                                   \
+    } while (0)
+__device__ PcStamps g_stamps_dummy;
+#else
+#define CCV_STAMP_AT(st, slot) do {} while (0)
+#endif
+
+// element d of a 5-entry kernel-argument array for a compile-time d
+template <int D>
+__device__ __forceinline__ double arg5(const double (&v)[5]) { return v[D]; }
+
+// lane state handed from the producer of block b to the producer of block b+1 (through LDS)
+template <int MODEL>
+struct PcState {
+    double x, y, yaw;
+    double roll, pitch;                                 // full body only
+    double p_v, p_rv, p_sdir, p_cdir, p_c2, p_c3, p_ac;  // full body: step t-1 quantities for the ZMP term (fb:468-486)
+};
+template <int MODEL>
+constexpr int kPcStateWords = MODEL == CCV_MPPI_FULL_BODY ? 12 : 3;
+
+template <int MODEL>
+struct PcShared {
+    double2 ab[kMaxH];
+    double c[kMaxH];
+    double p[2][kTU][2][kPcSamples];                       // (x,y) - pose of the 8 states of a block, double buffered
+    double st[2][kPcStateWords<MODEL>][kPcSamples];        // producer -> next producer
+    double cost[kPcWaves][kPcSamples];
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// producer: steps t0 .. t0+7 of one sample (sampling + predict_NextState + control costs).  FULL: every step of the
+// block carries controls (t0 + 8 <= H - 1), so the body is branch-free.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODEL, int MODE, bool FULL>
+__device__ __forceinline__ void pc_produce(const RolloutArgs& A, PcShared<MODEL>& sh, PcState<MODEL>& S, double& cost,
+                                           const int b, const int lane, const int k, const int kk, const bool live,
+                                           const uint32_t kg) {
+    constexpr int UD = udim_of(MODEL);
+    constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
+    constexpr bool COST = MODE != MODE_ROLLOUT;
+    const int H = A.H;
+    const int t0 = b * kTU;
+    const size_t pitch = (size_t)A.pitch;
+    const double dt = A.dt;
+    float zq[4] = {0.f, 0.f, 0.f, 0.f};
+    double4 nom = make_double4(0.0, 0.0, 0.0, 0.0);
+    static_for<kTU>([&](auto TT) {
+        constexpr int tt = decltype(TT)::value;
+        const int t = t0 + tt;
+        sh.p[b & 1][tt][0][lane] = S.x - A.x0[0];
+        sh.p[b & 1][tt][1][lane] = S.y - A.x0[1];
+        if (FULL || t < H) {
+            if constexpr (MODE != MODE_COST) {
+#if !defined(CCV_ABL_NO_STORE)
+                if (A.store_xy && live) {
+                    A.xs[(size_t)t * pitch + k] = S.x;
+                    A.ys[(size_t)t * pitch + k] = S.y;
+                }
+#endif
+            }
+            if (FULL || t < H - 1) {
+                double u[UD];
+                static_for<UD>([&](auto D) {
+                    constexpr int d = decltype(D)::value;
+                    constexpr int nloc = tt * UD + d;
+                    const int n = t0 * UD + nloc;   // row = step*UD + dim
+                    if constexpr (MODE == MODE_FUSED) {
+                        if constexpr ((nloc & 3) == 0) {
+                            // warm start u*[n .. n+3]: wave-uniform load, in flight while the Philox rounds run
+                            nom = *reinterpret_cast<const double4*>(A.nominal + n);
+#if defined(CCV_ABL_NO_NOISE)
+                            zq[0] = zq[1] = zq[2] = zq[3] = (float)(kg & 1023u) * 1e-3f - 0.5f;
+#else
+                            const Philox4 r = philox4x32_10(kg, (uint32_t)(n >> 2), A.iter_lo, A.iter_hi, A.seed_lo, A.seed_hi);
+                            box_muller_f32(r.x, r.y, zq[0], zq[1]);
+                            box_muller_f32(r.z, r.w, zq[2], zq[3]);
+#endif
+                        }
+                        constexpr int q = nloc & 3;
+                        const double mean = q == 0 ? nom.x : q == 1 ? nom.y : q == 2 ? nom.z : nom.w;
+                        // libstdc++ normal_distribution: ret * stddev + mean (dd:96-97), then clamp (dd:98-99)
+                        double v = (double)zq[q] * A.sigma + mean;
+                        v = clampd(v, arg5<d>(A.umin), arg5<d>(A.umax));
+                        if constexpr (FB && d == 2) {
+                            if (A.steer_off) v = 0.0;   // fb:517
+                        }
+                        u[d] = v;
+#if !defined(CCV_ABL_NO_STORE)
+                        if (live) A.u[(size_t)n * pitch + k] = v;
+#endif
+                    } else {
+                        u[d] = A.u[(size_t)n * pitch + kk];
+                    }
+                });
+                // ---- cost terms that do not need the window ----
+                if constexpr (COST) {
+                    if constexpr (!FB) {
+                        cost += A.w_v * ((u[0] - A.v_ref) * (u[0] - A.v_ref));   // dd:204-206
+                    } else {
+                        if (t < H - 2) {                                          // fb:409
+                            cost += A.w_v * (u[0] - A.v_ref) * (u[0] - A.v_ref);  // fb:413
+                            if (u[0] < 0.0) cost += A.w_back * u[0] * u[0];       // fb:420
+                        }
+                        if (t >= 1) {   // finish index t-1 <= H-3: ZMP (fb:468-485, 597-603) and roll-rate terms
+                            const double mgz = A.fb_mass * A.fb_gz;                               // (mass*gravity_).z
+                            const double drive_accel = (u[0] - S.p_v) / dt;                       // fb:469
+                            const double ay = drive_accel * S.p_sdir + S.p_ac * S.p_cdir;         // fb:473
+                            const double hgdot_x = (A.fb_Ixx * u[3] - A.fb_Ixx * S.p_rv) / dt;    // fb:479-481
+                            const double mo_x = (S.p_c2 * mgz + S.p_c3 * (A.fb_mass * ay)) - hgdot_x;  // fb:600
+                            const double zmp_y = mo_x / mgz;                                      // fb:601 (accel.z == 0)
+                            cost += A.w_zmp * zmp_y * zmp_y;                                      // fb:416
+                            cost += A.w_rollv * (u[3] - S.p_rv) * (u[3] - S.p_rv);                // fb:418
+                        }
+                    }
+                }
+                // ---- dynamics: explicit Euler (dd:104-109, sd:120-125, fb:445-452) ----
+                double hd = S.yaw;
+                if constexpr (MODEL != CCV_MPPI_DIFF_DRIVE) hd = S.yaw + u[2];
+                double sn, cs;
+#if defined(CCV_ABL_NO_SINCOS)
+                sn = hd * 0.5; cs = 1.0 - hd * 0.25;
+#else
+                sincos(hd, &sn, &cs);
+#endif
+                if constexpr (FB && COST) {
+                    double sd_, cd_, sr_, cr_;
+                    sincos(u[2], &sd_, &cd_);
+                    sincos(S.roll, &sr_, &cr_);
+                    S.p_sdir = sd_;
+                    S.p_cdir = cd_;
+                    S.p_c2 = -A.fb_L * sr_;                    // CoM.y (fb:482)
+                    S.p_c3 = A.fb_L * cos(S.pitch) * cr_;      // CoM.z
+                    S.p_ac = u[0] * u[1];                      // fb:471
+                    S.p_v = u[0];
+                    S.p_rv = u[3];
+                }
+                S.x = S.x + u[0] * cs * dt;
+                S.y = S.y + u[0] * sn * dt;
+                S.yaw = S.yaw + u[1] * dt;
+                if constexpr (FB) {
+                    S.roll = S.roll + u[3] * dt;
+                    S.pitch = S.pitch + u[4] * dt;
+                }
+            } else {
+                if constexpr (!FB && COST) {
+                    // t == H-1: the reference reads control index H-1, one past the end (dd:199,204): defined as 0.0 (Q1)
+                    cost += A.w_v * ((0.0 - A.v_ref) * (0.0 - A.v_ref));
+                }
+            }
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// producer, fast path for a block whose 8 steps all carry controls: the same arithmetic as pc_produce, arranged in
+// batches so that the independent chains of the 8 steps (Philox rounds, Box-Muller, sin/cos) sit in ONE basic block and
+// interleave -- a lone wave then issues back to back instead of waiting out each chain's latency.
+// Returns false (nothing done) when a heading is too large for the branch-free sin/cos; the caller then runs pc_produce.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODEL, int MODE>
+__device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShared<MODEL>& sh, PcState<MODEL>& S, double& cost,
+                                                   const int b, const int lane, const int k, const int kk, const bool live,
+                                                   const uint32_t kg
+#if defined(CCV_STAMP)
+                                                   , PcStamps& ST
+#endif
+                                                   ) {
+    constexpr int UD = udim_of(MODEL);
+    constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
+    constexpr bool COST = MODE != MODE_ROLLOUT;
+    constexpr int NCALL = kTU * UD / 4;
+    const int H = A.H;
+    const int t0 = b * kTU;
+    const size_t pitch = (size_t)A.pitch;
+    const double dt = A.dt;
+    // ---- 1. controls of the 8 steps
+    double u[kTU][UD];
+    if constexpr (MODE == MODE_FUSED) {
+        static_for<NCALL>([&](auto CC) {
+            constexpr int c = decltype(CC)::value;
+            const int n0 = t0 * UD + 4 * c;
+            const double4 nom = *reinterpret_cast<const double4*>(A.nominal + n0);   // wave-uniform warm start u*[n0..n0+3]
+            float z[4];
+#if defined(CCV_ABL_NO_NOISE)
+            z[0] = z[1] = z[2] = z[3] = (float)(kg & 1023u) * 1e-3f - 0.5f;
+#else
+            const Philox4 r = philox4x32_10(kg, (uint32_t)(n0 >> 2), A.iter_lo, A.iter_hi, A.seed_lo, A.seed_hi);
+            box_muller_f32(r.x, r.y, z[0], z[1]);
+            box_muller_f32(r.z, r.w, z[2], z[3]);
+#endif
+            const double mean[4] = {nom.x, nom.y, nom.z, nom.w};
+            static_for<4>([&](auto II) {
+                constexpr int i = decltype(II)::value;
+                constexpr int nloc = 4 * c + i;
+                constexpr int tt = nloc / UD, d = nloc % UD;
+                // libstdc++ normal_distribution: ret * stddev + mean (dd:96-97), then clamp (dd:98-99)
+                double v = (double)z[i] * A.sigma + mean[i];
+                v = clampd(v, arg5<d>(A.umin), arg5<d>(A.umax));
+                if constexpr (FB && d == 2) {
+                    if (A.steer_off) v = 0.0;   // fb:517
+                }
+                u[tt][d] = v;
+#if !defined(CCV_ABL_NO_STORE)
+                if (live) A.u[(size_t)(n0 + i) * pitch + k] = v;
+#endif
+            });
+        });
+    } else {
+#pragma unroll
+        for (int tt = 0; tt < kTU; ++tt)
+#pragma unroll
+            for (int d = 0; d < UD; ++d) u[tt][d] = A.u[(size_t)((t0 + tt) * UD + d) * pitch + kk];
+    }
+    CCV_STAMP_AT(ST, 0);
+    // ---- 2. heading (roll, pitch) recurrences: yaw[t+1] = yaw[t] + w[t]*dt (dd:108, fb:449-451)
+    double yawv[kTU + 1], rollv[FB ? kTU + 1 : 1], pitchv[FB ? kTU + 1 : 1];
+    yawv[0] = S.yaw;
+    if constexpr (FB) {
+        rollv[0] = S.roll;
+        pitchv[0] = S.pitch;
+    }
+#pragma unroll
+    for (int tt = 0; tt < kTU; ++tt) {
+        yawv[tt + 1] = yawv[tt] + u[tt][1] * dt;
+        if constexpr (FB) {
+            rollv[tt + 1] = rollv[tt] + u[tt][3] * dt;
+            pitchv[tt + 1] = pitchv[tt] + u[tt][4] * dt;
+        }
+    }
+    double hd[kTU];
+    bool ok = true;
+#pragma unroll
+    for (int tt = 0; tt < kTU; ++tt) {
+        hd[tt] = yawv[tt];
+        if constexpr (MODEL != CCV_MPPI_DIFF_DRIVE) hd[tt] = yawv[tt] + u[tt][2];
+        ok = ok && fast_trig_ok(hd[tt]);
+        if constexpr (FB && COST) ok = ok && fast_trig_ok(u[tt][2]) && fast_trig_ok(rollv[tt]) && fast_trig_ok(pitchv[tt]);
+    }
+    if (!__all(ok)) return false;   // wave-uniform: the whole block goes through the step-by-step path
+    CCV_STAMP_AT(ST, 1);
+    // ---- 3. sin/cos of the 8 headings (independent chains)
+    double sn[kTU], cs[kTU];
+#pragma unroll
+    for (int tt = 0; tt < kTU; ++tt) {
+#if defined(CCV_ABL_NO_SINCOS)
+        sn[tt] = hd[tt] * 0.5; cs[tt] = 1.0 - hd[tt] * 0.25;
+#else
+        fast_sincos(hd[tt], sn[tt], cs[tt]);
+#endif
+    }
+    CCV_STAMP_AT(ST, 2);
+    // ---- 4. cost terms that do not need the window
+    if constexpr (COST) {
+        if constexpr (!FB) {
+#pragma unroll
+            for (int tt = 0; tt < kTU; ++tt) cost += A.w_v * ((u[tt][0] - A.v_ref) * (u[tt][0] - A.v_ref));   // dd:204-206
+        } else {
+            const double mgz = A.fb_mass * A.fb_gz;   // (mass*gravity_).z
+#pragma unroll
+            for (int tt = 0; tt < kTU; ++tt) {
+                const int t = t0 + tt;
+                if (t < H - 2) {                                                      // fb:409
+                    cost += A.w_v * (u[tt][0] - A.v_ref) * (u[tt][0] - A.v_ref);      // fb:413
+                    if (u[tt][0] < 0.0) cost += A.w_back * u[tt][0] * u[tt][0];       // fb:420
+                }
+                if (t >= 1) {   // finish index t-1: ZMP (fb:468-485, 597-603) and roll-rate terms
+                    const double drive_accel = (u[tt][0] - S.p_v) / dt;                          // fb:469
+                    const double ay = drive_accel * S.p_sdir + S.p_ac * S.p_cdir;                // fb:473
+                    const double hgdot_x = (A.fb_Ixx * u[tt][3] - A.fb_Ixx * S.p_rv) / dt;       // fb:479-481
+                    const double mo_x = (S.p_c2 * mgz + S.p_c3 * (A.fb_mass * ay)) - hgdot_x;    // fb:600
+                    const double zmp_y = mo_x / mgz;                                             // fb:601
+                    cost += A.w_zmp * zmp_y * zmp_y;                                             // fb:416
+                    cost += A.w_rollv * (u[tt][3] - S.p_rv) * (u[tt][3] - S.p_rv);               // fb:418
+                }
+                double sd_, cd_, sr_, cr_, sp_, cp_;
+                fast_sincos(u[tt][2], sd_, cd_);
+                fast_sincos(rollv[tt], sr_, cr_);
+                fast_sincos(pitchv[tt], sp_, cp_);
+                S.p_sdir = sd_;
+                S.p_cdir = cd_;
+                S.p_c2 = -A.fb_L * sr_;             // CoM.y (fb:482)
+                S.p_c3 = A.fb_L * cp_ * cr_;        // CoM.z
+                S.p_ac = u[tt][0] * u[tt][1];       // fb:471
+                S.p_v = u[tt][0];
+                S.p_rv = u[tt][3];
+            }
+        }
+    }
+    // ---- 5. positions (dd:106-107), hand-off of (x,y) - pose to the consumer, x,y -> HBM
+    double x = S.x, y = S.y;
+#pragma unroll
+    for (int tt = 0; tt < kTU; ++tt) {
+        sh.p[b & 1][tt][0][lane] = x - A.x0[0];
+        sh.p[b & 1][tt][1][lane] = y - A.x0[1];
+        if constexpr (MODE != MODE_COST) {
+#if !defined(CCV_ABL_NO_STORE)
+            if (A.store_xy && live) {
+                A.xs[(size_t)(t0 + tt) * pitch + k] = x;
+                A.ys[(size_t)(t0 + tt) * pitch + k] = y;
+            }
+#endif
+        }
+        x = x + u[tt][0] * cs[tt] * dt;
+        y = y + u[tt][0] * sn[tt] * dt;
+    }
+    CCV_STAMP_AT(ST, 3);
+    S.x = x;
+    S.y = y;
+    S.yaw = yawv[kTU];
+    if constexpr (FB) {
+        S.roll = rollv[kTU];
+        S.pitch = pitchv[kTU];
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// consumer: min over the H window points of (a_j px + b_j py + c_j) for the NV states of one block, then the path cost.
+// Straight fp64 FMA/MIN; four window points per iteration so the LDS broadcast reads are covered and the compiler's
+// canonicalising max in front of fmin() is paid once per four minima.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NV, int MODEL>
+__device__ __forceinline__ void pc_consume(const RolloutArgs& A, const PcShared<MODEL>& sh, double& cost, const int b,
+                                           const int lane) {
+    const int H = A.H;
+    double px[NV], py[NV], m[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        px[i] = sh.p[b & 1][i][0][lane];
+        py[i] = sh.p[b & 1][i][1][lane];
+        m[i] = INFINITY;
+    }
+#pragma unroll 4
+    for (int j = 0; j < H; ++j) {
+        const double2 ab = sh.ab[j];
+        const double c = sh.c[j];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) m[i] = fmin(m[i], fma(ab.x, px[i], fma(ab.y, py[i], c)));
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        // d^2 = |p|^2 + min_j(...), gate d <= 100 (dd:185), cost += path_weight*d*d (dd:206)
+        double d2 = m[i] + fma(px[i], px[i], py[i] * py[i]);
+        d2 = fmin(fmax(d2, 0.0), 1.0e4);
+        cost += A.w_path * d2;
+    }
+}
+
+template <int MODEL, int MODE>
+__global__ __launch_bounds__(kPcWaves * 64, 4) void k_rollout_pc(const RolloutArgs A, const Window W) {
+    constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
+    constexpr bool COST = MODE != MODE_ROLLOUT;
+    __shared__ PcShared<MODEL> sh;
+    const int H = A.H;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (COST) {
+        for (int j = threadIdx.x; j < H; j += kPcWaves * 64) {
+            sh.ab[j] = make_double2(W.a[j], W.b[j]);
+            sh.c[j] = W.c[j];
+        }
+    }
+    const int k = blockIdx.x * kPcSamples + lane;
+    const bool live = k < A.K;
+    const int kk = live ? k : A.K - 1;
+    const uint32_t kg = (uint32_t)(A.k_offset + kk);
+    double cost = 0.0;
+    if constexpr (FB && COST) {
+        if (wv == 0) cost += A.w_yaw * (A.x0[2] - A.yaw_ref0) * (A.x0[2] - A.yaw_ref0);   // fb:408
+    }
+    const int nblocks = (H + kTU - 1) / kTU;
+    const int nstates = FB ? H - 2 : H;   // states that reach the path cost (dd:199 / fb:409)
+    __syncthreads();
+#if defined(CCV_STAMP)
+    PcStamps ST;
+    for (int i = 0; i < 8; ++i) ST.acc[i] = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ST.last)::"memory");
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int s = 0; s <= nblocks; ++s) {
+        CCV_STAMP_AT(ST, 7);
+        if (s < nblocks && (s & 1) == wv) {
+            // ---------------- produce block s
+            PcState<MODEL> S;
+            if (s == 0) {
+                S.x = A.x0[0];
+                S.y = A.x0[1];
+                S.yaw = A.x0[2];
+                S.roll = A.x0[3];
+                S.pitch = A.x0[4];
+                S.p_v = S.p_rv = S.p_sdir = S.p_c2 = S.p_c3 = S.p_ac = 0.0;
+                S.p_cdir = 1.0;
+            } else {
+                const double(*st)[kPcSamples] = sh.st[(s - 1) & 1];
+                S.x = st[0][lane];
+                S.y = st[1][lane];
+                S.yaw = st[2][lane];
+                if constexpr (FB) {
+                    S.roll = st[3][lane];
+                    S.pitch = st[4][lane];
+                    S.p_v = st[5][lane];
+                    S.p_rv = st[6][lane];
+                    S.p_sdir = st[7][lane];
+                    S.p_cdir = st[8][lane];
+                    S.p_c2 = st[9][lane];
+                    S.p_c3 = st[10][lane];
+                    S.p_ac = st[11][lane];
+                }
+            }
+            bool done = false;
+            if (s * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, s, lane, k, kk, live, kg
+#if defined(CCV_STAMP)
+                                                                              , ST
+#endif
+                                                                              );
+            if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, s, lane, k, kk, live, kg);
+            double(*st)[kPcSamples] = sh.st[s & 1];
+            st[0][lane] = S.x;
+            st[1][lane] = S.y;
+            st[2][lane] = S.yaw;
+            if constexpr (FB) {
+                st[3][lane] = S.roll;
+                st[4][lane] = S.pitch;
+                st[5][lane] = S.p_v;
+                st[6][lane] = S.p_rv;
+                st[7][lane] = S.p_sdir;
+                st[8][lane] = S.p_cdir;
+                st[9][lane] = S.p_c2;
+                st[10][lane] = S.p_c3;
+                st[11][lane] = S.p_ac;
+            }
+            CCV_STAMP_AT(ST, 4);
+        }
+        if constexpr (COST) {
+            if (s >= 1 && ((s - 1) & 1) == wv) {
+                // ---------------- consume block s-1
+                const int b = s - 1;
+#if defined(CCV_ABL_NO_DIST)
+                const int nv = 0;
+#else
+                const int nv = min(kTU, nstates - b * kTU);
+#endif
+                if (nv == kTU) pc_consume<kTU, MODEL>(A, sh, cost, b, lane);
+                else if (nv > 0) {
+                    switch (nv) {
+                        case 7: pc_consume<7, MODEL>(A, sh, cost, b, lane); break;
+                        case 6: pc_consume<6, MODEL>(A, sh, cost, b, lane); break;
+                        case 5: pc_consume<5, MODEL>(A, sh, cost, b, lane); break;
+                        case 4: pc_consume<4, MODEL>(A, sh, cost, b, lane); break;
+                        case 3: pc_consume<3, MODEL>(A, sh, cost, b, lane); break;
+                        case 2: pc_consume<2, MODEL>(A, sh, cost, b, lane); break;
+                        default: pc_consume<1, MODEL>(A, sh, cost, b, lane); break;
+                    }
+                }
+                CCV_STAMP_AT(ST, 5);
+            }
+        }
+        __syncthreads();
+        CCV_STAMP_AT(ST, 6);
+    }
+#if defined(CCV_STAMP)
+    if (A.dbg && lane == 0 && blockIdx.x == 3) {
+        for (int i = 0; i < 8; ++i) A.dbg[wv * 8 + i] = ST.acc[i];
+    }
+    if (A.dbg && lane == 0 && wv == 0 && blockIdx.x < 4096) {
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        unsigned int hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        unsigned int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+        A.dbg[64 + blockIdx.x * 3 + 0] = rt0;
+        A.dbg[64 + blockIdx.x * 3 + 1] = rt1;
+        A.dbg[64 + blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
+    if constexpr (COST) {
+        sh.cost[wv][lane] = cost;
+        __syncthreads();
+        if (wv == 0 && live) {
+            const double total = sh.cost[0][lane] + sh.cost[1][lane];
+            A.cost[k] = total;
+            A.w[k] = exp(-total / A.lambda);   // dd:219 (no min-cost shift)
+        }
+    }
+}
+
+}  // namespace ccv

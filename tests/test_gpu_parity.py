@@ -178,18 +178,27 @@ def test_fused_equals_stagewise_bitwise(name):
     assert st_a.sum_w == st_b.sum_w
 
 
-def test_scalar_window_variant_matches_lds_variant(monkeypatch):
-    p, kind = CASES["dd_K256_H50_sinusoid_C2"]
+@pytest.mark.parametrize("name", ["dd_K256_H50_sinusoid_C2", "sd_K256_H50_sinusoid_C3", "fb_K128_H80_dkan_C4"])
+def test_kernel_variants_agree(monkeypatch, name):
+    """The production kernel (4 waves share 64 samples) against the plain one-sample-per-lane variants kept for
+    experiments (CCV_MPPI_KERNEL=v1, LDS or scalar-load window): same samples, costs equal up to summation order."""
+    p, kind = CASES[name]
     path = helpers.oracle_path(kind)
     state = start_state(p, path)
     xr, yr, yaw = helpers.oracle_window(p, path, state)
     a = MPPIController(p)
-    monkeypatch.setenv("CCV_MPPI_WINDOW", "scalar")
+    monkeypatch.setenv("CCV_MPPI_KERNEL", "v1")
     b = MPPIController(p)
-    u_a = a.iterate(state, p.dt, xr, yr, yaw[0], 3, 0, want_stats=False)
-    u_b = b.iterate(state, p.dt, xr, yr, yaw[0], 3, 0, want_stats=False)
-    np.testing.assert_array_equal(a.read_costs(), b.read_costs())
-    np.testing.assert_array_equal(u_a, u_b)
+    monkeypatch.setenv("CCV_MPPI_WINDOW", "scalar")
+    c = MPPIController(p)
+    res = [g.iterate(state, p.dt, xr, yr, yaw[0], 3, 0, want_stats=False) for g in (a, b, c)]
+    np.testing.assert_array_equal(b.read_costs(), c.read_costs())
+    np.testing.assert_array_equal(a.read_controls(), b.read_controls())
+    # the production kernel uses a branch-free sin/cos (<= 1-2 ulp from OCML's): states agree to rounding
+    np.testing.assert_allclose(a.read_candidates(), b.read_candidates(), rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(a.read_costs(), b.read_costs(), rtol=1e-12)
+    np.testing.assert_allclose(res[0], res[1], rtol=1e-10, atol=1e-14)
+    np.testing.assert_array_equal(res[1], res[2])
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,144 @@
+// Micro-benchmark of the O(K*H^2) core (calc_MinDistance, dd:183-192): cycles per (trajectory point, window point)
+// pair for several formulations of the inner loop.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+#include <type_traits>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+constexpr int TU = 8;
+constexpr int REP = 64;
+constexpr int MAXH = 128;
+
+struct Win { double a[MAXH], b[MAXH], c[MAXH]; };
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+__device__ __forceinline__ double vmin64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// V0: plain fmin, LDS reads at use (what the first kernel did)
+__device__ __forceinline__ void v0(const double (&px)[TU], const double (&py)[TU], double (&m)[TU], int H, const double2* sab, const double* sc, const Win&) {
+#pragma unroll 2
+    for (int j = 0; j < H; ++j) {
+        const double2 ab = sab[j]; const double c = sc[j];
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; m[i] = fmin(m[i], fma(ab.x, px[i], fma(ab.y, py[i], c))); });
+    }
+}
+// V1: asm min + rotation (prefetch next from LDS)
+__device__ __forceinline__ void v1(const double (&px)[TU], const double (&py)[TU], double (&m)[TU], int H, const double2* sab, const double* sc, const Win&) {
+    double a = sab[0].x, b = sab[0].y, c = sc[0];
+    for (int j = 0; j < H; ++j) {
+        const int jn = (j + 1 < H) ? j + 1 : j;
+        const double2 abn = sab[jn]; const double cn = sc[jn];
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+        double t[TU];
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; t[i] = fma(b, py[i], c); });
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; t[i] = fma(a, px[i], t[i]); });
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; m[i] = vmin64(m[i], t[i]); });
+        a = abn.x; b = abn.y; c = cn;
+    }
+}
+// V2: asm min, two points per iteration, prefetch the next two
+__device__ __forceinline__ void v2(const double (&px)[TU], const double (&py)[TU], double (&m)[TU], int H, const double2* sab, const double* sc, const Win&) {
+    double a0 = sab[0].x, b0 = sab[0].y, c0 = sc[0], a1 = sab[1].x, b1 = sab[1].y, c1 = sc[1];
+    for (int j = 0; j < H; j += 2) {   // H even here
+        const int jn = (j + 2 < H) ? j + 2 : j;
+        const double2 abn0 = sab[jn], abn1 = sab[jn + 1]; const double cn0 = sc[jn], cn1 = sc[jn + 1];
+        asm volatile("" : "+v"(a0), "+v"(b0), "+v"(c0), "+v"(a1), "+v"(b1), "+v"(c1));
+        double t[TU], s[TU];
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; t[i] = fma(b0, py[i], c0); });
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; s[i] = fma(b1, py[i], c1); });
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; t[i] = fma(a0, px[i], t[i]); });
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; s[i] = fma(a1, px[i], s[i]); });
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; m[i] = vmin64(m[i], t[i]); });
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; m[i] = vmin64(m[i], s[i]); });
+        a0 = abn0.x; b0 = abn0.y; c0 = cn0; a1 = abn1.x; b1 = abn1.y; c1 = cn1;
+    }
+}
+// V3: coefficients straight from the kernel-argument segment (scalar loads), asm min
+__device__ __forceinline__ void v3(const double (&px)[TU], const double (&py)[TU], double (&m)[TU], int H, const double2*, const double*, const Win& W) {
+#pragma unroll 2
+    for (int j = 0; j < H; ++j) {
+        const double a = W.a[j], b = W.b[j], c = W.c[j];
+        double t[TU];
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; t[i] = fma(b, py[i], c); });
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; t[i] = fma(a, px[i], t[i]); });
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; m[i] = vmin64(m[i], t[i]); });
+    }
+}
+// V4: plain fmin but 4 points per iteration (amortises the canonicalising max), LDS
+__device__ __forceinline__ void v4(const double (&px)[TU], const double (&py)[TU], double (&m)[TU], int H, const double2* sab, const double* sc, const Win&) {
+#pragma unroll 4
+    for (int j = 0; j < H; ++j) {
+        const double2 ab = sab[j]; const double c = sc[j];
+        sfor<TU>([&](auto I) { constexpr int i = decltype(I)::value; m[i] = fmin(m[i], fma(ab.x, px[i], fma(ab.y, py[i], c))); });
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k(double* out, int H, unsigned long long* cyc, const Win W) {
+    __shared__ double2 sab[MAXH];
+    __shared__ double sc[MAXH];
+    for (int j = threadIdx.x; j < H + 2; j += 256) { sab[j] = make_double2(W.a[j], W.b[j]); sc[j] = W.c[j]; }
+    __syncthreads();
+    double px[TU], py[TU], m[TU];
+#pragma unroll
+    for (int i = 0; i < TU; ++i) { px[i] = 0.01 * threadIdx.x + i; py[i] = 0.02 * threadIdx.x - i; m[i] = 1e300; }
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < REP; ++r) {
+        if (V == 0) v0(px, py, m, H, sab, sc, W);
+        else if (V == 1) v1(px, py, m, H, sab, sc, W);
+        else if (V == 2) v2(px, py, m, H, sab, sc, W);
+        else if (V == 3) v3(px, py, m, H, sab, sc, W);
+        else v4(px, py, m, H, sab, sc, W);
+#pragma unroll
+        for (int i = 0; i < TU; ++i) px[i] += 1e-9 * m[i];   // dependency between repetitions
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < TU; ++i) s += m[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
+template <int V>
+void run(const char* name, int wps, int H, const Win& W) {
+    const int blocks = 256 * wps;
+    double* out; unsigned long long* cyc;
+    CHECK(hipMalloc(&out, sizeof(double) * blocks * 256));
+    CHECK(hipMalloc(&cyc, 8));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, out, H, cyc, W);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    const int reps = 5;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, out, H, cyc, W);
+    CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long hc; CHECK(hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost));
+    const double pairs_per_wave = (double)REP * H * TU;
+    const double us = ms * 1000.0 / reps;
+    printf("%-26s waves/SIMD %d: kernel %7.1f us  %.2f ns per pair per SIMD  | wave 0: %.2f ticks per pair\n", name, wps, us,
+           us * 1000.0 / (pairs_per_wave * wps), (double)hc / pairs_per_wave);
+    CHECK(hipFree(out)); CHECK(hipFree(cyc));
+}
+
+int main() {
+    Win W;
+    for (int j = 0; j < MAXH; ++j) { W.a[j] = -2.0 * 0.12 * j; W.b[j] = 0.3 * j; W.c[j] = 0.01 * j * j; }
+    const int H = 50;
+    for (int wps : {1, 2, 4}) {
+        run<0>("V0 fmin, load-at-use", wps, H, W);
+        run<4>("V4 fmin, unroll 4", wps, H, W);
+        run<1>("V1 asm min + rotate", wps, H, W);
+        run<2>("V2 asm min, 2 pts/iter", wps, H, W);
+        run<3>("V3 scalar loads", wps, H, W);
+        printf("\n");
+    }
+    return 0;
+}
