@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--samples-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-state-store", action="store_true", help="skip the KxH x,y buffer (not the headline)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel hipEvents in the timed region")
     args = ap.parse_args()
 
     import torch
@@ -156,7 +157,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    ctl.timing_enable(True)        # hipEvents around the rollout kernel and the whole launch sequence, on `stream`
+    # hipEvents around the rollout kernel and the whole launch sequence of every 8th step, on `stream` (recording on every
+    # step costs ~8 us/step of launch serialisation; the sampled launches are inside the timed region)
+    ctl.timing_enable(not args.no_kernel_events, every=8)
     ctl.timing_read(reset=True)
     fence()
     t0 = time.perf_counter()

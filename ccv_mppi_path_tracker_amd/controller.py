@@ -169,8 +169,8 @@ class MPPIController:
         self._check(self.lib.ccv_mppi_apply_partials_enqueue(self._h, C.c_void_p(dev_ptr)))
 
     # ---- measurement ----
-    def timing_enable(self, on=True):
-        self._check(self.lib.ccv_mppi_timing_enable(self._h, 1 if on else 0))
+    def timing_enable(self, on=True, every=1):
+        self._check(self.lib.ccv_mppi_timing_enable(self._h, (max(1, int(every)) if on else 0)))
 
     def timing_read(self, reset=True):
         a, b, n = C.c_double(), C.c_double(), C.c_int64()

@@ -17,7 +17,8 @@ using namespace ccv;
 
 struct ccv_mppi_handle {
     ccv_mppi_config cfg{};
-    int udim = 0, K = 0, H = 0, R = 0, pitch = 0, nchunks = 0;
+    int udim = 0, K = 0, H = 0, R = 0, pitch = 0, nchunks = 0, nblocks = 0;
+    int nparts_last = 0;   // number of partial columns the last cost evaluation produced (fused: workgroups, else: chunks)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // device buffers
@@ -46,8 +47,11 @@ struct ccv_mppi_handle {
     // CCV_MPPI_WINDOW=scalar -> its scalar-load window variant; default = k_rollout_pc
     int lds_window = 1;
     int coop = 1;
+    double inj_absmax[CCV_MPPI_MAX_UDIM] = {0, 0, 0, 0, 0};   // largest |control| per dimension in the buffer (sampled: clamp bound)
     // timing
     bool timing = false;
+    int timing_every = 1;     // record events on every n-th iteration only
+    int64_t timing_count = 0;
     std::vector<hipEvent_t> ev;  // triples: start, after rollout, end
     size_t ev_used = 0;
     double t_roll_sum = 0.0, t_iter_sum = 0.0;
@@ -133,6 +137,10 @@ void fill_args(const ccv_mppi_handle* h, RolloutArgs& A, const double* x0, doubl
     A.ys = h->d_ys;
     A.cost = h->d_cost;
     A.w = h->d_w;
+    A.partial = h->d_partial;
+    A.statpart = h->d_statpart;
+    A.nparts = h->nblocks;
+    A.fuse_update = 0;
     A.dbg = h->d_dbg;
 }
 
@@ -167,7 +175,35 @@ void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const 
     }
 }
 
-int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int mode) {
+// k_rollout_pc uses a branch-free sin/cos that is valid for |angle| <= kFastTrigLimit.  Every heading a sample can
+// reach is bounded by the start angle plus (H-1) steps at the largest control magnitude, so the decision is made here,
+// once per call; anything else (huge or non-finite angles, unbounded injected controls) runs the plain
+// one-sample-per-lane kernel with OCML's sincos.
+bool fast_trig_safe(const ccv_mppi_handle* h, const RolloutArgs& A, int mode) {
+    const int ud = h->udim;
+    double umax[CCV_MPPI_MAX_UDIM];
+    for (int d = 0; d < ud; ++d) {
+        umax[d] = mode == MODE_FUSED ? std::fmax(std::fabs(h->cfg.u_min[d]), std::fabs(h->cfg.u_max[d])) : h->inj_absmax[d];
+    }
+    const double steps = (double)(h->H - 1) * std::fabs(A.dt);
+    double bound = std::fabs(A.x0[2]) + steps * umax[1];
+    if (h->cfg.model != CCV_MPPI_DIFF_DRIVE) bound += umax[2];
+    if (h->cfg.model == CCV_MPPI_FULL_BODY) {
+        bound = std::fmax(bound, std::fabs(A.x0[3]) + steps * umax[3]);
+        bound = std::fmax(bound, std::fabs(A.x0[4]) + steps * umax[4]);
+    }
+    return bound <= kFastTrigLimit;   // false for NaN
+}
+
+int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A_in, const Window& W, int mode) {
+    RolloutArgs A = A_in;
+    const int saved = h->coop;
+    if (h->coop && !fast_trig_safe(h, A, mode)) h->coop = 0;
+    struct Restore { ccv_mppi_handle* h; int v; ~Restore() { h->coop = v; } } restore{h, saved};
+    // the production kernel also reduces its workgroup's share of sum w and sum w*u (no second pass over the controls);
+    // the underflow-safe MIN_SHIFT mode needs the global minimum first and keeps the separate update kernels
+    A.fuse_update = (h->coop && mode != MODE_ROLLOUT && !(h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT)) ? 1 : 0;
+    if (mode != MODE_ROLLOUT) h->nparts_last = A.fuse_update ? h->nblocks : 0;
     switch (h->cfg.model) {
         case CCV_MPPI_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_DIFF_DRIVE>(h, A, W, mode); break;
         case CCV_MPPI_STEERING_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_STEERING_DIFF_DRIVE>(h, A, W, mode); break;
@@ -190,22 +226,27 @@ int launch_sample(ccv_mppi_handle* h, const RolloutArgs& A) {
 
 // weights -> [sum w, sum w*u] (-> u* when `normalise`); vec_out may be a caller-owned device buffer.
 int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out) {
-    if (h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT) {
-        hipLaunchKernelGGL(k_min_cost, dim3(1), dim3(1024), 0, h->stream, h->d_cost, h->K, h->d_cmin);
-        hipLaunchKernelGGL(k_reweight, dim3((h->K + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_cost, h->d_cmin,
-                           h->cfg.lambda, h->K, h->d_w);
+    int nparts = h->nparts_last;
+    if (nparts == 0) {
+        // not fused (one-sample-per-lane fallback kernel or MIN_SHIFT): stream w and the controls once more
+        if (h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT) {
+            hipLaunchKernelGGL(k_min_cost, dim3(1), dim3(1024), 0, h->stream, h->d_cost, h->K, h->d_cmin);
+            hipLaunchKernelGGL(k_reweight, dim3((h->K + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_cost, h->d_cmin,
+                               h->cfg.lambda, h->K, h->d_w);
+        }
+        UpdateArgs U;
+        U.u = h->d_u;
+        U.w = h->d_w;
+        U.cost = h->d_cost;
+        U.partial = h->d_partial;
+        U.statpart = h->d_statpart;
+        U.K = h->K;
+        U.pitch = h->pitch;
+        U.R = h->R;
+        U.nchunks = h->nchunks;
+        hipLaunchKernelGGL(k_update_partials, dim3(h->nchunks, h->R + 1), dim3(kBlock), 0, h->stream, U);
+        nparts = h->nchunks;
     }
-    UpdateArgs U;
-    U.u = h->d_u;
-    U.w = h->d_w;
-    U.cost = h->d_cost;
-    U.partial = h->d_partial;
-    U.statpart = h->d_statpart;
-    U.K = h->K;
-    U.pitch = h->pitch;
-    U.R = h->R;
-    U.nchunks = h->nchunks;
-    hipLaunchKernelGGL(k_update_partials, dim3(h->nchunks, h->R + 1), dim3(kBlock), 0, h->stream, U);
     FinalizeArgs F;
     F.partial = h->d_partial;
     F.statpart = h->d_statpart;
@@ -213,7 +254,7 @@ int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out) {
     F.vec = vec_out ? vec_out : h->d_vec;
     F.stats = h->d_stats;
     F.R = h->R;
-    F.nchunks = h->nchunks;
+    F.nchunks = nparts;
     F.normalise = normalise ? 1 : 0;
     hipLaunchKernelGGL(k_finalize, dim3((h->R + 3) / 4), dim3(kBlock), 0, h->stream, F);
     HIP_TRY(h, hipGetLastError());
@@ -269,16 +310,17 @@ int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const dou
     A.store_xy = (h->cfg.flags & CCV_MPPI_FLAG_NO_STATE_STORE) ? 0 : 1;
     A.do_cost = 1;
     size_t slot = 0;
-    if (h->timing) {
+    const bool timed = h->timing && (h->timing_count++ % h->timing_every) == 0;
+    if (timed) {
         int rc = timing_begin(h, slot);
         if (rc) return rc;
     }
     int rc = launch_rollout(h, A, W, MODE_FUSED);
     if (rc) return rc;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[slot + 1], h->stream));
+    if (timed) HIP_TRY(h, hipEventRecord(h->ev[slot + 1], h->stream));
     rc = launch_update(h, normalise, vec_out);
     if (rc) return rc;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[slot + 2], h->stream));
+    if (timed) HIP_TRY(h, hipEventRecord(h->ev[slot + 2], h->stream));
     std::memcpy(h->st_x0, A.x0, sizeof(h->st_x0));
     h->st_dt = dt;
     h->have_controls = h->have_rollout = h->have_weights = true;
@@ -345,6 +387,7 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     h->R = (h->H - 1) * h->udim;
     h->pitch = round_up(h->K, 64);
     h->nchunks = (h->K + kChunk - 1) / kChunk;
+    h->nblocks = (h->K + kPcSamples - 1) / kPcSamples;
     const char* env = getenv("CCV_MPPI_WINDOW");
     h->lds_window = !(env && std::strcmp(env, "scalar") == 0);
     const char* kenv = getenv("CCV_MPPI_KERNEL");
@@ -368,8 +411,8 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
         {&h->d_ys, (size_t)h->H * P},
         {&h->d_cost, P},
         {&h->d_w, P},
-        {&h->d_partial, (size_t)(h->R + 1) * h->nchunks},
-        {&h->d_statpart, (size_t)h->nchunks * 3},
+        {&h->d_partial, (size_t)(h->R + 1) * (h->nblocks > h->nchunks ? h->nblocks : h->nchunks)},
+        {&h->d_statpart, (size_t)(h->nblocks > h->nchunks ? h->nblocks : h->nchunks) * 3},
         {&h->d_vec, (size_t)h->R + 1},
         {&h->d_stats, 4},
         {&h->d_cmin, 1},
@@ -500,6 +543,7 @@ int ccv_mppi_sample(ccv_mppi_handle* h, uint64_t seed, uint64_t iter) {
     int rc = launch_sample(h, A);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int d = 0; d < h->udim; ++d) h->inj_absmax[d] = std::fmax(std::fabs(h->cfg.u_min[d]), std::fabs(h->cfg.u_max[d]));
     h->have_controls = true;
     h->have_rollout = h->have_weights = false;
     return CCV_MPPI_OK;
@@ -509,8 +553,14 @@ int ccv_mppi_inject_controls(ccv_mppi_handle* h, const double* u_samples) {
     if (!h || !u_samples) return CCV_MPPI_ERR_INVALID_ARG;
     // [K][(H-1)][u_dim] -> rows n = t*u_dim + d of pitch doubles
     std::vector<double> tmp((size_t)h->R * h->pitch, 0.0);
+    for (int d = 0; d < CCV_MPPI_MAX_UDIM; ++d) h->inj_absmax[d] = 0.0;
     for (int i = 0; i < h->K; ++i)
-        for (int n = 0; n < h->R; ++n) tmp[(size_t)n * h->pitch + i] = u_samples[(size_t)i * h->R + n];
+        for (int n = 0; n < h->R; ++n) {
+            const double v = u_samples[(size_t)i * h->R + n];
+            tmp[(size_t)n * h->pitch + i] = v;
+            const int d = n % h->udim;
+            if (!(std::fabs(v) <= h->inj_absmax[d])) h->inj_absmax[d] = std::fabs(v);   // NaN sticks
+        }
     HIP_TRY(h, hipMemcpyAsync(h->d_u, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_controls = true;
@@ -637,6 +687,8 @@ int ccv_mppi_timing_enable(ccv_mppi_handle* h, int32_t on) {
     int rc = timing_collect(h);
     if (rc) return rc;
     h->timing = on != 0;
+    h->timing_every = on > 1 ? on : 1;   // on = n > 1: sample every n-th iteration
+    h->timing_count = 0;
     return CCV_MPPI_OK;
 }
 

@@ -60,6 +60,9 @@ struct RolloutArgs {
     double* ys;
     double* cost;
     double* w;
+    double* partial;    // fused update: [(R+1)][nparts] per-workgroup sums of w and w*u (null: not fused)
+    double* statpart;   // [nparts][3]: min cost, max cost, zero-weight count
+    int32_t nparts, fuse_update;
     unsigned long long* dbg;   // diagnostic builds only (CCV_STAMP): per-phase cycle sums
 };
 
@@ -410,21 +413,35 @@ struct FinalizeArgs {
 // One wave per row n: lanes read the chunk partials of the row (fixed order => bitwise reproducible), wave-reduce them,
 // and re-derive S = sum w the same way, so no cross-block hand-off is needed.  u*[n] = V_n / S
 // (== sum_i (w_i/S) u_i of dd:222,234 up to rounding; S == 0 gives NaN exactly as dd:222 does).
+__device__ __forceinline__ double lane_partial_sum(const double* row, int n, int lane) {
+    // up to 1024 partials per pass: all 16 loads of a lane are issued before the first add (one memory latency, not 16)
+    double acc = 0.0;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + lane + 64 * i;
+            v[i] = c < n ? row[c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += v[i];
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);   // row handled by this wave
-    double s = 0.0;
-    for (int c = lane; c < A.nchunks; c += 64) s += A.partial[(size_t)A.R * A.nchunks + c];
+    const int nrow = n < A.R ? n : A.R;
+    // S = sum w and this wave's row are fetched together
+    double s = lane_partial_sum(A.partial + (size_t)A.R * A.nchunks, A.nchunks, lane);
+    double v = lane_partial_sum(A.partial + (size_t)nrow * A.nchunks, A.nchunks, lane);
     s = wave_sum(s);
     s = __shfl(s, 0, 64);
-    if (n < A.R) {
-        double v = 0.0;
-        for (int c = lane; c < A.nchunks; c += 64) v += A.partial[(size_t)n * A.nchunks + c];
-        v = wave_sum(v);
-        if (lane == 0) {
-            A.vec[1 + n] = v;
-            if (A.normalise) A.nominal[n] = v / s;
-        }
+    v = wave_sum(v);
+    if (n < A.R && lane == 0) {
+        A.vec[1 + n] = v;
+        if (A.normalise) A.nominal[n] = v / s;
     }
     if (n == 0) {
         double mn = INFINITY, mx = -INFINITY, nz = 0.0;

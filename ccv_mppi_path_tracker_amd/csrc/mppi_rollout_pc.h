@@ -62,8 +62,8 @@ constexpr int kPcStateWords = MODEL == CCV_MPPI_FULL_BODY ? 12 : 3;
 
 template <int MODEL>
 struct PcShared {
-    double2 ab[kMaxH];
-    double c[kMaxH];
+    double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
+    double c[kMaxH + 4];
     double p[2][kTU][2][kPcSamples];                       // (x,y) - pose of the 8 states of a block, double buffered
     double st[2][kPcStateWords<MODEL>][kPcSamples];        // producer -> next producer
     double cost[kPcWaves][kPcSamples];
@@ -162,16 +162,17 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, PcShared<MODEL>
 #if defined(CCV_ABL_NO_SINCOS)
                 sn = hd * 0.5; cs = 1.0 - hd * 0.25;
 #else
-                sincos(hd, &sn, &cs);
+                fast_sincos(hd, sn, cs);
 #endif
                 if constexpr (FB && COST) {
-                    double sd_, cd_, sr_, cr_;
-                    sincos(u[2], &sd_, &cd_);
-                    sincos(S.roll, &sr_, &cr_);
+                    double sd_, cd_, sr_, cr_, sp_, cp_;
+                    fast_sincos(u[2], sd_, cd_);
+                    fast_sincos(S.roll, sr_, cr_);
+                    fast_sincos(S.pitch, sp_, cp_);
                     S.p_sdir = sd_;
                     S.p_cdir = cd_;
                     S.p_c2 = -A.fb_L * sr_;                    // CoM.y (fb:482)
-                    S.p_c3 = A.fb_L * cos(S.pitch) * cr_;      // CoM.z
+                    S.p_c3 = A.fb_L * cp_ * cr_;               // CoM.z
                     S.p_ac = u[0] * u[1];                      // fb:471
                     S.p_v = u[0];
                     S.p_rv = u[3];
@@ -197,7 +198,6 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, PcShared<MODEL>
 // producer, fast path for a block whose 8 steps all carry controls: the same arithmetic as pc_produce, arranged in
 // batches so that the independent chains of the 8 steps (Philox rounds, Box-Muller, sin/cos) sit in ONE basic block and
 // interleave -- a lone wave then issues back to back instead of waiting out each chain's latency.
-// Returns false (nothing done) when a heading is too large for the branch-free sin/cos; the caller then runs pc_produce.
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODEL, int MODE>
 __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShared<MODEL>& sh, PcState<MODEL>& S, double& cost,
@@ -269,16 +269,14 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
             pitchv[tt + 1] = pitchv[tt] + u[tt][4] * dt;
         }
     }
+    // (the host only selects this kernel when every reachable angle is inside the branch-free sin/cos range:
+    //  ccv_mppi_capi.hip fast_trig_safe())
     double hd[kTU];
-    bool ok = true;
 #pragma unroll
     for (int tt = 0; tt < kTU; ++tt) {
         hd[tt] = yawv[tt];
         if constexpr (MODEL != CCV_MPPI_DIFF_DRIVE) hd[tt] = yawv[tt] + u[tt][2];
-        ok = ok && fast_trig_ok(hd[tt]);
-        if constexpr (FB && COST) ok = ok && fast_trig_ok(u[tt][2]) && fast_trig_ok(rollv[tt]) && fast_trig_ok(pitchv[tt]);
     }
-    if (!__all(ok)) return false;   // wave-uniform: the whole block goes through the step-by-step path
     CCV_STAMP_AT(ST, 1);
     // ---- 3. sin/cos of the 8 headings (independent chains)
     double sn[kTU], cs[kTU];
@@ -364,7 +362,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
 template <int NV, int MODEL>
 __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const PcShared<MODEL>& sh, double& cost, const int b,
                                            const int lane) {
-    const int H = A.H;
+    const int H4 = (A.H + 3) & ~3;   // the window is padded with c = +inf: four points per iteration, no remainder
     double px[NV], py[NV], m[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -372,12 +370,14 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const PcShared<
         py[i] = sh.p[b & 1][i][1][lane];
         m[i] = INFINITY;
     }
-#pragma unroll 4
-    for (int j = 0; j < H; ++j) {
-        const double2 ab = sh.ab[j];
-        const double c = sh.c[j];
+    for (int j = 0; j < H4; j += 4) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) m[i] = fmin(m[i], fma(ab.x, px[i], fma(ab.y, py[i], c)));
+        for (int jj = 0; jj < 4; ++jj) {
+            const double2 ab = sh.ab[j + jj];
+            const double c = sh.c[j + jj];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) m[i] = fmin(m[i], fma(ab.x, px[i], fma(ab.y, py[i], c)));
+        }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -385,6 +385,54 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const PcShared<
         double d2 = m[i] + fma(px[i], px[i], py[i] * py[i]);
         d2 = fmin(fmax(d2, 0.0), 1.0e4);
         cost += A.w_path * d2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused first half of determine_OptimalSolution() (dd:228-237): this workgroup's share of sum_i w_i and
+// sum_i w_i * u_i[t][d] for every control row, so that the K x (H-1) x u_dim controls are not streamed from HBM a second
+// time by a separate kernel -- they are re-read here, by the CU that wrote them (L2 / Infinity Cache hits).
+// Rows are dealt to the two waves; a wave reduces 15 rows at a time through LDS: every lane drops w*u for each row,
+// then lane (r, q) adds 16 of the 64 entries of row r and two shuffles finish the row.  Fixed order => reproducible.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODEL>
+__device__ __forceinline__ void pc_partial_update(const RolloutArgs& A, PcShared<MODEL>& sh, const double wgt, const double total,
+                                                  const int lane, const int wv, const int kk, const bool live) {
+    constexpr int UD = udim_of(MODEL);
+    constexpr int RB = 15;                 // rows per batch: 15 * 65 doubles fit this wave's half of sh.p
+    constexpr int STRIDE = kPcSamples + 1; // padded row: lanes (r, q) hit different banks
+    const int R = (A.H - 1) * UD;
+    const size_t pitch = (size_t)A.pitch;
+    double* buf = &sh.p[wv][0][0][0];      // 8 * 2 * 64 = 1024 doubles per wave, free after the last consume
+    const int rr = lane >> 2, q = lane & 3;
+    __syncthreads();                       // everyone is done with sh.p
+    for (int base = wv * RB; base < R; base += kPcWaves * RB) {
+        const int nrows = min(RB, R - base);
+        for (int r = 0; r < nrows; ++r) buf[r * STRIDE + lane] = wgt * A.u[(size_t)(base + r) * pitch + kk];
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed (wave-private buffer)
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+        if (rr < nrows) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc += buf[rr * STRIDE + q * 16 + i];
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (rr < nrows && q == 0) A.partial[(size_t)(base + rr) * A.nparts + blockIdx.x] = acc;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (wv == 0) {
+        // sum of weights + cost statistics of this workgroup
+        const double sw = wave_sum(wgt);
+        const double mn = wave_min(live ? total : INFINITY);
+        const double mx = wave_max(live ? total : -INFINITY);
+        const double nz = wave_sum((live && wgt == 0.0) ? 1.0 : 0.0);
+        if (lane == 0) {
+            A.partial[(size_t)R * A.nparts + blockIdx.x] = sw;
+            A.statpart[blockIdx.x * 3 + 0] = mn;
+            A.statpart[blockIdx.x * 3 + 1] = mx;
+            A.statpart[blockIdx.x * 3 + 2] = nz;
+        }
     }
 }
 
@@ -397,9 +445,10 @@ __global__ __launch_bounds__(kPcWaves * 64, 4) void k_rollout_pc(const RolloutAr
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if constexpr (COST) {
-        for (int j = threadIdx.x; j < H; j += kPcWaves * 64) {
-            sh.ab[j] = make_double2(W.a[j], W.b[j]);
-            sh.c[j] = W.c[j];
+        const int H4 = (H + 3) & ~3;
+        for (int j = threadIdx.x; j < H4; j += kPcWaves * 64) {
+            sh.ab[j] = j < H ? make_double2(W.a[j], W.b[j]) : make_double2(0.0, 0.0);
+            sh.c[j] = j < H ? W.c[j] : INFINITY;
         }
     }
     const int k = blockIdx.x * kPcSamples + lane;
@@ -423,6 +472,9 @@ __global__ __launch_bounds__(kPcWaves * 64, 4) void k_rollout_pc(const RolloutAr
         CCV_STAMP_AT(ST, 7);
         if (s < nblocks && (s & 1) == wv) {
             // ---------------- produce block s
+#if defined(CCV_EXP_PRIO)
+            __builtin_amdgcn_s_setprio(CCV_EXP_PRIO);
+#endif
             PcState<MODEL> S;
             if (s == 0) {
                 S.x = A.x0[0];
@@ -476,6 +528,9 @@ __global__ __launch_bounds__(kPcWaves * 64, 4) void k_rollout_pc(const RolloutAr
         if constexpr (COST) {
             if (s >= 1 && ((s - 1) & 1) == wv) {
                 // ---------------- consume block s-1
+#if defined(CCV_EXP_PRIO)
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 const int b = s - 1;
 #if defined(CCV_ABL_NO_DIST)
                 const int nv = 0;
@@ -516,11 +571,13 @@ __global__ __launch_bounds__(kPcWaves * 64, 4) void k_rollout_pc(const RolloutAr
     if constexpr (COST) {
         sh.cost[wv][lane] = cost;
         __syncthreads();
+        const double total = sh.cost[0][lane] + sh.cost[1][lane];
+        const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
         if (wv == 0 && live) {
-            const double total = sh.cost[0][lane] + sh.cost[1][lane];
             A.cost[k] = total;
-            A.w[k] = exp(-total / A.lambda);   // dd:219 (no min-cost shift)
+            A.w[k] = wgt;
         }
+        if (A.fuse_update) pc_partial_update<MODEL>(A, sh, wgt, total, lane, wv, kk, live);
     }
 }
 

@@ -149,8 +149,9 @@ int ccv_mppi_iterate_partials_enqueue(ccv_mppi_handle* h, const double* x0, doub
 int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partials);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */
-/* When enabled every iteration records hipEvents around the dominant kernel and the whole launch sequence;
- * ccv_mppi_timing_read returns the accumulated device times since the last reset (it synchronises). */
+/* on = 1: every iteration records hipEvents around the dominant kernel and the whole launch sequence; on = n > 1: every
+ * n-th iteration only (keeps the event overhead out of a throughput measurement); 0: off.
+ * ccv_mppi_timing_read returns the accumulated device times of the recorded iterations since the last reset (it synchronises). */
 int ccv_mppi_timing_enable(ccv_mppi_handle* h, int32_t on);
 int ccv_mppi_timing_read(ccv_mppi_handle* h, double* rollout_us_sum, double* iter_us_sum, int64_t* n_iters,
                          int32_t reset);

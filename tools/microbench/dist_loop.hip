@@ -79,6 +79,43 @@ __device__ __forceinline__ void v4(const double (&px)[TU], const double (&py)[TU
     }
 }
 
+// V5: the 24 instructions of one window point as ONE asm block (8 FMA, 8 FMA, 8 MIN: dependent ops 8 issue slots apart, no
+// canonicalising max), next point's coefficients prefetched from LDS by rotation
+#define TRIPLE_ASM(a, b, c)                                                                                              \
+    asm volatile(                                                                                                        \
+        "v_fma_f64 %8, %24, %16, %26\n\tv_fma_f64 %9, %24, %17, %26\n\tv_fma_f64 %10, %24, %18, %26\n\tv_fma_f64 %11, %24, %19, %26\n\t" \
+        "v_fma_f64 %12, %24, %20, %26\n\tv_fma_f64 %13, %24, %21, %26\n\tv_fma_f64 %14, %24, %22, %26\n\tv_fma_f64 %15, %24, %23, %26\n\t" \
+        "v_fma_f64 %8, %25, %27, %8\n\tv_fma_f64 %9, %25, %28, %9\n\tv_fma_f64 %10, %25, %29, %10\n\tv_fma_f64 %11, %25, %30, %11\n\t"   \
+        "v_fma_f64 %12, %25, %31, %12\n\tv_fma_f64 %13, %25, %32, %13\n\tv_fma_f64 %14, %25, %33, %14\n\tv_fma_f64 %15, %25, %34, %15\n\t" \
+        "v_min_f64 %0, %0, %8\n\tv_min_f64 %1, %1, %9\n\tv_min_f64 %2, %2, %10\n\tv_min_f64 %3, %3, %11\n\t"                         \
+        "v_min_f64 %4, %4, %12\n\tv_min_f64 %5, %5, %13\n\tv_min_f64 %6, %6, %14\n\tv_min_f64 %7, %7, %15"                            \
+        : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "=&v"(t[0]),   \
+          "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])                      \
+        : "v"(py[0]), "v"(py[1]), "v"(py[2]), "v"(py[3]), "v"(py[4]), "v"(py[5]), "v"(py[6]), "v"(py[7]), "v"(b), "v"(a), \
+          "v"(c), "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(px[4]), "v"(px[5]), "v"(px[6]), "v"(px[7]))
+__device__ __forceinline__ void v5(const double (&px)[TU], const double (&py)[TU], double (&m)[TU], int H, const double2* sab, const double* sc, const Win&) {
+    double a = sab[0].x, b = sab[0].y, c = sc[0];
+    double t[TU];
+    for (int j = 0; j < H; ++j) {
+        const int jn = (j + 1 < H) ? j + 1 : j;
+        const double2 abn = sab[jn]; const double cn = sc[jn];
+        TRIPLE_ASM(a, b, c);
+        a = abn.x; b = abn.y; c = cn;
+    }
+}
+// V6: as V5, two points per iteration (prefetch distance = 48 instructions)
+__device__ __forceinline__ void v6(const double (&px)[TU], const double (&py)[TU], double (&m)[TU], int H, const double2* sab, const double* sc, const Win&) {
+    double a0 = sab[0].x, b0 = sab[0].y, c0 = sc[0], a1 = sab[1].x, b1 = sab[1].y, c1 = sc[1];
+    double t[TU];
+    for (int j = 0; j < H; j += 2) {
+        const int jn = (j + 2 < H) ? j + 2 : j;
+        const double2 abn0 = sab[jn], abn1 = sab[jn + 1]; const double cn0 = sc[jn], cn1 = sc[jn + 1];
+        TRIPLE_ASM(a0, b0, c0);
+        TRIPLE_ASM(a1, b1, c1);
+        a0 = abn0.x; b0 = abn0.y; c0 = cn0; a1 = abn1.x; b1 = abn1.y; c1 = cn1;
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void k(double* out, int H, unsigned long long* cyc, const Win W) {
     __shared__ double2 sab[MAXH];
@@ -94,6 +131,8 @@ __global__ __launch_bounds__(256) void k(double* out, int H, unsigned long long*
         else if (V == 1) v1(px, py, m, H, sab, sc, W);
         else if (V == 2) v2(px, py, m, H, sab, sc, W);
         else if (V == 3) v3(px, py, m, H, sab, sc, W);
+        else if (V == 5) v5(px, py, m, H, sab, sc, W);
+        else if (V == 6) v6(px, py, m, H, sab, sc, W);
         else v4(px, py, m, H, sab, sc, W);
 #pragma unroll
         for (int i = 0; i < TU; ++i) px[i] += 1e-9 * m[i];   // dependency between repetitions
@@ -138,6 +177,8 @@ int main() {
         run<1>("V1 asm min + rotate", wps, H, W);
         run<2>("V2 asm min, 2 pts/iter", wps, H, W);
         run<3>("V3 scalar loads", wps, H, W);
+        run<5>("V5 asm block/pt", wps, H, W);
+        run<6>("V6 asm block, 2 pts/iter", wps, H, W);
         printf("\n");
     }
     return 0;

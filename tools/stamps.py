@@ -29,7 +29,8 @@ occ = (C.c_int * 4)()
 g.lib.ccv_mppi_debug_occupancy(occ)
 print("occupancy API: blocks/CU=%d numRegs=%d lds=%d scratch=%d" % tuple(occ))
 names = ["P noise+u", "P recur", "P sincos", "P cost+xy", "P rest", "C dist", "barrier", "loop"]
-a = np.array(list(out), dtype=np.float64).reshape(4, 8)[:2]
+a = np.array(list(out), dtype=np.float64).reshape(4, 8)
+print("waves: 0 = dynamics + noise share, 1..3 = distance + noise share")
 print("K=%d %s   cycles per wave (block 3), columns = waves 0..3" % (K, wl))
 for i, n in enumerate(names):
     print("%-8s " % n + "  ".join("%8.0f" % v for v in a[:, i]))
@@ -54,3 +55,10 @@ key = xcc * 10000 + se * 1000 + sh_ * 100 + cu
 uniq, counts = np.unique(key, return_counts=True)
 print("distinct (xcc,se,sh,cu): %d; blocks per CU min/max: %d/%d; xcc histogram: %s" % (len(uniq), counts.min(), counts.max(),
       list(np.bincount(xcc, minlength=8))))
+dur = end_us - start_us
+for x in range(8):
+    sel = xcc == x
+    print("xcc %d: blocks %d  end median %.1f max %.1f  duration median %.1f" % (x, sel.sum(), np.median(end_us[sel]), end_us[sel].max(), np.median(dur[sel])))
+order = np.argsort(end_us)
+print("slowest 8 blocks (id, xcc, se, cu, end):", [(int(i), int(xcc[i]), int(se[i]), int(cu[i]), round(float(end_us[i]), 1)) for i in order[-8:]])
+print("fastest 8 blocks:", [(int(i), int(xcc[i]), int(se[i]), int(cu[i]), round(float(end_us[i]), 1)) for i in order[:8]])
