@@ -31,11 +31,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 
 
 def algorithmic_bytes(T, udim):
-    """B = 8*[2*(T-1)*u_dim + 2*T + 2] per rollout for the whole iteration; the rollout kernel's
-    share is controls written once + x,y written once + weight written once."""
+    """B = 8*[2*(T-1)*u_dim + 2*T + 2] per rollout: controls written once and read once for the weighted
+    update, x,y written once, weight written and read once.  The rollout kernel does all of it (the update's partial sums
+    are fused into its epilogue), so B is also the dominant kernel's algorithmic traffic."""
     whole = 8 * (2 * (T - 1) * udim + 2 * T + 2)
-    rollout_kernel = 8 * ((T - 1) * udim + 2 * T + 1)
-    return whole, rollout_kernel
+    return whole, whole
 
 
 def script_inputs(amd, w, n):
@@ -132,22 +132,20 @@ def main():
     k_total = k_local * world
     ctl = amd.MPPIController(p, device=local_rank, num_samples=k_local, sample_offset=rank * k_local,
                              no_state_store=args.no_state_store)
+    from ccv_mppi_path_tracker_amd import sharded
     stream = torch.cuda.current_stream()
     ctl.set_stream(stream.cuda_stream)
     inputs = script_inputs(amd, w, 64)
-    partials = torch.zeros(ctl.partials_size(), dtype=torch.float64, device="cuda")
-    pptr = partials.data_ptr()
     seed = 42
+    # N > 1: per-GPU partials [sum w, sum w*u] -> one small RCCL all-reduce over xGMI -> every rank divides (no host sync)
+    driver = sharded.ShardedMPPI(sharded.DevicePartials(ctl)) if world > 1 else None
 
     def step(i):
         s, xr, yr, yaw0 = inputs[i % len(inputs)]
         if world == 1:
             ctl.iterate_enqueue(s, p.dt, xr, yr, yaw0, seed, i)
         else:
-            # per-GPU partials [sum w, sum w*u] -> one small RCCL all-reduce over xGMI -> every rank divides
-            ctl.iterate_partials_enqueue(s, p.dt, xr, yr, yaw0, seed, i, pptr)
-            dist.all_reduce(partials)
-            ctl.apply_partials_enqueue(pptr)
+            driver.iterate(s, p.dt, xr, yr, yaw0, seed, i)
 
     def fence():
         if world > 1:
@@ -199,7 +197,7 @@ def main():
                        "state_store": not args.no_state_store},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_rollout_cost", "kernel_avg_us": 1e6 * roll_avg_s,
+                         "kernel": "k_rollout_pc", "kernel_avg_us": 1e6 * roll_avg_s,
                          "algorithmic_bytes_per_launch": B_roll * k_local,
                          "iteration_avg_us": 1e6 * iter_avg_s,
                          "iteration_algorithmic_bytes": B * k_local,

@@ -84,6 +84,17 @@ SIGNATURES = {
                                        C.c_int32]),
     "ccv_mppi_path_dkan": (C.c_int, [C.c_double, _dp, _dp, C.c_int32]),
     "ccv_mppi_plant_step": (C.c_int, [C.c_int32, _dp, _dp, C.c_double]),
+    # include/ccv_mppi_node.hpp (extern "C" part): the ROS-free mirror of the reference controller classes
+    "ccv_mppi_node_create": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), _dp, C.c_int, C.c_int, C.POINTER(_H)]),
+    "ccv_mppi_node_destroy": (C.c_int, [_H]),
+    "ccv_mppi_node_set_path": (C.c_int, [_H, _dp, _dp, C.c_int]),
+    "ccv_mppi_node_set_state": (C.c_int, [_H, _dp]),
+    "ccv_mppi_node_set_seed": (C.c_int, [_H, C.c_uint64]),
+    "ccv_mppi_node_set_fused": (C.c_int, [_H, C.c_int]),
+    "ccv_mppi_node_run_once": (C.c_int, [_H, C.c_double, _dp]),
+    "ccv_mppi_node_get_optimal": (C.c_int, [_H, _dp]),
+    "ccv_mppi_node_get_ref_path": (C.c_int, [_H, _dp]),
+    "ccv_mppi_node_get_optimal_path": (C.c_int, [_H, _dp]),
 }
 
 _lib = None

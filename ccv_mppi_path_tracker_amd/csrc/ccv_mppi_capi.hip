@@ -2,6 +2,7 @@
 // Host side only orchestrates: allocate once, build the window coefficients, launch, copy u* back.
 // There is deliberately no CPU fallback: every entry point fails with CCV_MPPI_ERR_NO_DEVICE / _HIP.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -52,7 +53,8 @@ struct ccv_mppi_handle {
     bool timing = false;
     int timing_every = 1;     // record events on every n-th iteration only
     int64_t timing_count = 0;
-    std::vector<hipEvent_t> ev;  // triples: start, after rollout, end
+    std::vector<hipEvent_t> ev;  // triples: rollout kernel begin, rollout kernel end, end of the launch sequence
+    hipEvent_t ev_kernel_start = nullptr, ev_kernel_stop = nullptr;   // set for the duration of a timed launch
     size_t ev_used = 0;
     double t_roll_sum = 0.0, t_iter_sum = 0.0;
     int64_t t_n = 0;
@@ -159,6 +161,12 @@ template <int MODEL>
 void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int mode) {
     if (h->coop) {
         const dim3 cgrid((h->K + kPcSamples - 1) / kPcSamples), cblock(kPcWaves * 64);
+        if (mode == MODE_FUSED && h->ev_kernel_start) {
+            // timed launch: the events are attached to the dispatch itself (kernel begin / end timestamps)
+            hipExtLaunchKernelGGL((k_rollout_pc<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, h->ev_kernel_start,
+                                  h->ev_kernel_stop, 0, A, W);
+            return;
+        }
         if (mode == MODE_FUSED) hipLaunchKernelGGL((k_rollout_pc<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, A, W);
         else if (mode == MODE_ROLLOUT) hipLaunchKernelGGL((k_rollout_pc<MODEL, MODE_ROLLOUT>), cgrid, cblock, 0, h->stream, A, W);
         else hipLaunchKernelGGL((k_rollout_pc<MODEL, MODE_COST>), cgrid, cblock, 0, h->stream, A, W);
@@ -256,7 +264,7 @@ int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out) {
     F.R = h->R;
     F.nchunks = nparts;
     F.normalise = normalise ? 1 : 0;
-    hipLaunchKernelGGL(k_finalize, dim3((h->R + 3) / 4), dim3(kBlock), 0, h->stream, F);
+    hipLaunchKernelGGL(k_finalize, dim3((h->R + 1 + 3) / 4), dim3(kBlock), 0, h->stream, F);
     HIP_TRY(h, hipGetLastError());
     return CCV_MPPI_OK;
 }
@@ -271,7 +279,6 @@ int timing_begin(ccv_mppi_handle* h, size_t& slot) {
         }
     }
     h->ev_used += 3;
-    HIP_TRY(h, hipEventRecord(h->ev[slot], h->stream));
     return CCV_MPPI_OK;
 }
 
@@ -315,9 +322,13 @@ int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const dou
         int rc = timing_begin(h, slot);
         if (rc) return rc;
     }
+    if (timed) {
+        h->ev_kernel_start = h->ev[slot];
+        h->ev_kernel_stop = h->ev[slot + 1];
+    }
     int rc = launch_rollout(h, A, W, MODE_FUSED);
+    h->ev_kernel_start = h->ev_kernel_stop = nullptr;
     if (rc) return rc;
-    if (timed) HIP_TRY(h, hipEventRecord(h->ev[slot + 1], h->stream));
     rc = launch_update(h, normalise, vec_out);
     if (rc) return rc;
     if (timed) HIP_TRY(h, hipEventRecord(h->ev[slot + 2], h->stream));

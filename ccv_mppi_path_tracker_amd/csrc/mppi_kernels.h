@@ -431,7 +431,9 @@ __device__ __forceinline__ double lane_partial_sum(const double* row, int n, int
 
 __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);   // row handled by this wave
+    // rows 0..R-1: one wave each; the wave with n == R (first wave past the rows) gathers the cost statistics instead, so
+    // that their loads run beside the row reductions rather than after one of them
+    const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int nrow = n < A.R ? n : A.R;
     // S = sum w and this wave's row are fetched together
     double s = lane_partial_sum(A.partial + (size_t)A.R * A.nchunks, A.nchunks, lane);
@@ -443,12 +445,24 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
         A.vec[1 + n] = v;
         if (A.normalise) A.nominal[n] = v / s;
     }
-    if (n == 0) {
+    if (n == A.R) {
         double mn = INFINITY, mx = -INFINITY, nz = 0.0;
-        for (int c = lane; c < A.nchunks; c += 64) {
-            mn = fmin(mn, A.statpart[c * 3 + 0]);
-            mx = fmax(mx, A.statpart[c * 3 + 1]);
-            nz += A.statpart[c * 3 + 2];
+        for (int c0 = 0; c0 < A.nchunks; c0 += 1024) {
+            double a[16], b[16], z[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {   // all loads first: one memory latency per 1024 partials
+                const int c = c0 + lane + 64 * i;
+                const bool in = c < A.nchunks;
+                a[i] = in ? A.statpart[c * 3 + 0] : INFINITY;
+                b[i] = in ? A.statpart[c * 3 + 1] : -INFINITY;
+                z[i] = in ? A.statpart[c * 3 + 2] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                mn = fmin(mn, a[i]);
+                mx = fmax(mx, b[i]);
+                nz += z[i];
+            }
         }
         mn = wave_min(mn);
         mx = wave_max(mx);

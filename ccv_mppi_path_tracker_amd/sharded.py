@@ -1,0 +1,64 @@
+"""K sharded over the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" on CPU for tests).
+
+Rank g owns the samples [g*K_local, (g+1)*K_local) and draws their noise with GLOBAL sample ids, so the union of the
+shards is exactly the single-device sample set.  Every rank receives the same (pose, dt, window) and produces the
+unnormalised partial vector [sum_i w_i, sum_i w_i*u_i[t][d]] of its shard; ONE all-reduce(sum) of 1 + (H-1)*u_dim
+doubles (<= 3.2 KB) per iteration follows, then every rank divides -- which reproduces the reference's normalised
+weighted mean (src/diff_drive_mppi.cpp:216-237) without a min-cost shift.  The message is latency-bound; nothing else
+crosses the links.
+"""
+import numpy as np
+
+
+def shard_bounds(num_samples_global, world_size, rank):
+    """Contiguous, equal shards (the driver sizes K as a multiple of the world size)."""
+    if num_samples_global % world_size:
+        raise ValueError("num_samples (%d) must be a multiple of the world size (%d)" % (num_samples_global, world_size))
+    k_local = num_samples_global // world_size
+    return rank * k_local, k_local
+
+
+class ShardedMPPI:
+    """Drives one shard.  `backend` computes the local partials and applies the reduced ones:
+         backend.local_partials(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration) -> torch tensor [1 + (H-1)*u_dim] (float64)
+         backend.apply(reduced tensor)                                         -> None (u* <- V / S)
+       The production backend is DevicePartials below (GPU, no host sync); the CPU tests plug the oracle in."""
+
+    def __init__(self, backend, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.backend = backend
+        self.group = group
+
+    def iterate(self, x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration):
+        part = self.backend.local_partials(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration)
+        if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
+            self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.backend.apply(part)
+        return part
+
+
+class DevicePartials:
+    """GPU backend: the partials live in a torch tensor on the controller's device; everything is enqueued on the
+    current torch stream (no host synchronisation between the rollout, the all-reduce and the division)."""
+
+    def __init__(self, controller):
+        import torch
+        self.torch = torch
+        self.ctl = controller
+        self.buf = torch.zeros(controller.partials_size(), dtype=torch.float64, device="cuda")
+        controller.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def local_partials(self, x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration):
+        self.ctl.iterate_partials_enqueue(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration, self.buf.data_ptr())
+        return self.buf
+
+    def apply(self, reduced):
+        self.ctl.apply_partials_enqueue(reduced.data_ptr())
+
+
+def combine_partials(parts):
+    """Reference combination on the host (tests): sum of the per-shard vectors, then u* = V / S."""
+    tot = np.sum(np.asarray(parts, dtype=np.float64), axis=0)
+    return tot[1:] / tot[0], tot

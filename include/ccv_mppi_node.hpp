@@ -1,0 +1,146 @@
+// ccv_mppi_node.hpp -- ROS-free host mirror of the three reference controller classes.
+//
+// The reference's "API" is the class/topic surface of its ROS nodes.  ROS is not installed in this image,
+// so these classes keep the reference's class names, method names, member names and parameter names/defaults, replace
+// the ROS message types by plain structs, and implement the four hot methods
+//     sampling(), predict_States(), calc_Weights(), determine_OptimalSolution()
+// by calls into the C ABI of include/ccv_mppi.h.  A maintainer of the ROS package applies the same four bodies to the
+// real node.  Reference locations:
+//     DiffDriveMPPI          include/ccv_mppi_path_tracker/diff_drive_mppi.h:52-155, src/diff_drive_mppi.cpp
+//     SteeringDiffDriveMPPI  include/ccv_mppi_path_tracker/steering_diff_drive_mppi.h:56-163, src/steering_diff_drive_mppi.cpp
+//     FullBodyMPPI           include/ccv_mppi_path_tracker/full_body_mppi.h:68-231, src/full_body_mppi.cpp
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ccv_mppi.h"
+
+namespace ccv_mppi_node {
+
+// stand-ins for the message types the hot path touches (only the fields it reads or writes)
+struct Path {                       // nav_msgs::Path: poses[i].pose.position.{x,y}
+    std::vector<double> x, y;
+    size_t size() const { return x.size(); }
+};
+struct Twist {                      // geometry_msgs::Twist: linear.x, angular.z
+    double linear_x = 0.0, angular_z = 0.0;
+};
+struct CmdPoseByRadian {            // ccv_dynamixel_msgs::CmdPoseByRadian
+    double steer_l = 0.0, steer_r = 0.0, fore = 0.0, rear = 0.0, roll = 0.0;
+};
+struct RobotState {                 // current_pose_ (dd/sd) or current_state_ (fb): x, y, yaw[, roll, pitch]
+    double x = 0.0, y = 0.0, yaw = 0.0, roll = 0.0, pitch = 0.0;
+};
+
+// nh_.param(name, var, default): parameters come from a string->double map (what the ROS parameter server would hold)
+using ParamMap = std::map<std::string, double>;
+
+// Common machinery of the three controllers: everything the reference duplicates verbatim in its three classes.
+class MPPIBase {
+public:
+    virtual ~MPPIBase();
+    MPPIBase(const MPPIBase&) = delete;
+    MPPIBase& operator=(const MPPIBase&) = delete;
+
+    // ---- subscriber side ----
+    void pathCallback(const Path& msg);            // dd:48-52
+    void set_CurrentState(const RobotState& s);    // what get_Transform() (dd:314-329) / get_CurrentState() (fb:528-567) produce
+    void set_Seed(uint64_t seed) { seed_ = seed; }
+
+    // ---- one pass of the body of run() (dd:346-361): false while no path has been received ----
+    bool run_once(double dt);
+
+    // ---- the hot methods, in the reference's call order (dd:352-358) ----
+    void sampling();                     // dd:81-102   -> ccv_mppi_sample
+    void predict_States();               // dd:111-124  -> ccv_mppi_rollout
+    void calc_Weights();                 // dd:212-223  -> calc_RefPath() + ccv_mppi_weights
+    void determine_OptimalSolution();    // dd:225-246  -> ccv_mppi_update
+    // host prologue
+    int get_CurrentIndex();              // dd:126-140
+    void calc_RefPath();                 // dd:156-181
+    // command post-processing
+    void publish_CmdVel();               // dd:248-253
+    virtual void publish_CmdPos() = 0;   // dd:255-263 / sd:273-296 / fb:246-275
+
+    // ---- results ("published" values) ----
+    Twist cmd_vel_;
+    CmdPoseByRadian cmd_pos_;
+    std::vector<double> x_ref_, y_ref_, yaw_ref_;       // ref_path_ (dd:142-154)
+    std::vector<double> optimal_solution;                // controls [(H-1)][u_dim]  (RobotStates optimal_solution, dd.h:100)
+    ccv_mppi_stats last_stats_{};
+    int last_status_ = CCV_MPPI_OK;
+    std::vector<double> candidate_path(int count, int stride);   // publish_CandidatePath() feed (dd:265-294): [count][H][2]
+    std::vector<double> optimal_path();                           // publish_OptimalPath() (dd:295-312): [H-1][3] x,y,yaw
+
+    int horizon() const { return horizon_; }
+    int num_samples() const { return (int)num_samples_; }
+    int udim() const { return udim_; }
+    bool use_fused_ = true;   // run_once(): one fused device iteration (default) or the four stage-wise calls
+
+protected:
+    MPPIBase(int model, const ParamMap& params, int device);
+    static double param(const ParamMap& p, const char* name, double dflt);
+    void create_handle(const ccv_mppi_config& cfg);
+
+    int model_;
+    int udim_;
+    ccv_mppi_handle* handle_ = nullptr;
+    // parameters (names as in the reference)
+    int horizon_ = 15;
+    double num_samples_ = 1000.0;
+    double control_noise_ = 0.5, exploration_noise_ = 0.5, lambda_ = 1.0;
+    double v_max_ = 1.2, w_max_ = 2.0, steer_max_ = 0.0, v_min_ = -1.2, w_min_ = -2.0, steer_min_ = 0.0;
+    double v_ref_ = 0.8, path_weight_ = 1.0, v_weight_ = 1.0;
+    double dt_ = 0.1, resolution_ = 0.1, pitch_offset_ = 0.0;
+    double tread_ = 0.501, wheel_radius_ = 0.1435;
+    // state
+    Path path_;
+    RobotState current_state_;
+    bool path_received_ = false;
+    int current_index_ = 0;
+    uint64_t seed_ = 42, iteration_ = 0;
+};
+
+class DiffDriveMPPI : public MPPIBase {
+public:
+    explicit DiffDriveMPPI(const ParamMap& params = {}, int device = 0);
+    void publish_CmdPos() override;   // dd:255-263
+};
+
+class SteeringDiffDriveMPPI : public MPPIBase {
+public:
+    explicit SteeringDiffDriveMPPI(const ParamMap& params = {}, int device = 0);
+    void publish_CmdPos() override;   // sd:273-296
+};
+
+class FullBodyMPPI : public MPPIBase {
+public:
+    explicit FullBodyMPPI(const ParamMap& params = {}, int device = 0);
+    void publish_CmdPos() override;   // fb:246-275
+private:
+    double roll_max_, roll_min_, pitch_max_, pitch_min_, roll_v_max_, roll_v_min_, pitch_v_max_, pitch_v_min_;
+    double zmp_weight_, roll_v_weight_, back_weight_, yaw_weight_;
+    bool roll_off_, steer_off_;
+};
+
+}  // namespace ccv_mppi_node
+
+// ---- plain C access to the classes above (ctypes / tests) ----------------------------------------------------------
+extern "C" {
+typedef struct ccv_mppi_node_t ccv_mppi_node_t;
+/* model: CCV_MPPI_DIFF_DRIVE ...; params: n (name, value) pairs */
+int ccv_mppi_node_create(int model, const char* const* names, const double* values, int n, int device, ccv_mppi_node_t** out);
+int ccv_mppi_node_destroy(ccv_mppi_node_t* node);
+int ccv_mppi_node_set_path(ccv_mppi_node_t* node, const double* x, const double* y, int n);
+int ccv_mppi_node_set_state(ccv_mppi_node_t* node, const double* state5);
+int ccv_mppi_node_set_seed(ccv_mppi_node_t* node, uint64_t seed);
+int ccv_mppi_node_set_fused(ccv_mppi_node_t* node, int fused);
+/* one run() pass; returns 1 if a command was produced, 0 while waiting for the path, <0 on error.
+ * cmd_out: linear.x, angular.z, steer_l, steer_r, fore, rear, roll */
+int ccv_mppi_node_run_once(ccv_mppi_node_t* node, double dt, double* cmd_out7);
+int ccv_mppi_node_get_optimal(ccv_mppi_node_t* node, double* u_out);      /* [(H-1)][u_dim] */
+int ccv_mppi_node_get_ref_path(ccv_mppi_node_t* node, double* xyyaw_out); /* [H][3] */
+int ccv_mppi_node_get_optimal_path(ccv_mppi_node_t* node, double* xyyaw_out); /* [H-1][3] */
+}

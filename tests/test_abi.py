@@ -12,7 +12,7 @@ from ccv_mppi_path_tracker_amd import build, capi, configs
 from ccv_mppi_path_tracker_amd.controller import MPPIController, MPPIError, make_config
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADERS = [os.path.join(ROOT, "include", h) for h in ("ccv_mppi.h", "ccv_mppi_host.h")]
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("ccv_mppi.h", "ccv_mppi_host.h", "ccv_mppi_node.hpp")]
 
 
 def _declared():
@@ -20,6 +20,9 @@ def _declared():
     for h in HEADERS:
         src = open(h).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        if h.endswith(".hpp"):
+            src = src[src.index('extern "C"'):]   # only the plain-C part of the C++ header is an ABI
         names |= set(re.findall(r"\b(ccv_mppi_[a-z_0-9]+)\s*\(", src))
     return names
 
@@ -29,7 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert os.path.exists(path)
     lib = C.CDLL(path)
     declared = _declared()
-    assert len(declared) >= 28
+    assert len(declared) >= 38
     for name in declared:
         assert hasattr(lib, name), "libccv_mppi_hip.so does not export %s" % name
     assert declared == set(capi.SIGNATURES), "ctypes table and headers disagree"
@@ -97,3 +100,17 @@ def test_product_never_touches_the_oracle():
     code = "import sys; import ccv_mppi_path_tracker_amd as m; m.capi.load(); " \
            "assert not [k for k in sys.modules if k.split('.')[0] == 'oracle']"
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_node_api_rejects_bad_arguments_and_has_no_fallback():
+    import ctypes as C
+    import torch
+    lib = capi.load()
+    h = capi._H()
+    assert lib.ccv_mppi_node_create(9, None, None, 0, 0, C.byref(h)) == capi.ERR_INVALID_ARG
+    assert lib.ccv_mppi_node_create(0, None, None, 0, 0, None) == capi.ERR_INVALID_ARG
+    assert lib.ccv_mppi_node_destroy(None) == capi.ERR_INVALID_ARG
+    if not torch.cuda.is_available():
+        from ccv_mppi_path_tracker_amd import ControllerNode
+        with pytest.raises(MPPIError):
+            ControllerNode("diff_drive", {"num_samples": 64})

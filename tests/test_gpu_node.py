@@ -1,0 +1,128 @@
+"""GPU tests of the ROS-free controller node classes (include/ccv_mppi_node.hpp): one run() pass per call, closed loop
+against the oracle, stage-wise vs fused call paths, command post-processing (publish_CmdVel / publish_CmdPos)."""
+import numpy as np
+import pytest
+
+import helpers
+import ccv_mppi_path_tracker_amd as amd
+from ccv_mppi_path_tracker_amd import ControllerNode, capi, configs
+
+pytestmark = pytest.mark.gpu
+DEG = np.pi / 180.0
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(gpu_required):
+    capi.load()
+
+
+def _oracle_params(model, over):
+    base = {"diff_drive": configs.diff_drive_defaults, "steering_diff_drive": configs.steering_defaults,
+            "full_body": configs.full_body_defaults}[model](int(over["num_samples"]), int(over["horizon"]))
+    kw = {}
+    if "v_ref" in over:
+        kw["v_ref"] = over["v_ref"]
+    if "path_weight" in over:
+        kw["path_weight"] = over["path_weight"]
+    if "v_max" in over:
+        kw["u_max"] = (over["v_max"],) + base.u_max[1:]
+    for k in ("zmp_weight", "roll_v_weight", "back_weight", "yaw_weight"):
+        if k in over:
+            kw[k] = over[k]
+    return base.with_(**kw)
+
+
+CASES = [
+    ("diff_drive", "sinusoid", {"num_samples": 512, "horizon": 30, "v_ref": 1.2, "v_max": 2.0, "path_weight": 10.0}),
+    ("steering_diff_drive", "sinusoid", {"num_samples": 512, "horizon": 20, "v_ref": 1.2, "v_max": 2.0, "path_weight": 10.0}),
+    ("full_body", "dkan", {"num_samples": 512, "horizon": 24, "v_ref": 2.0, "v_max": 2.0, "path_weight": 10.0,
+                           "zmp_weight": 10.0, "roll_v_weight": 0.5, "yaw_weight": 2.0}),
+]
+
+
+@pytest.mark.parametrize("model,kind,over", CASES)
+def test_node_closed_loop_matches_oracle(model, kind, over):
+    p = _oracle_params(model, over)
+    px, py = amd.make_path(kind)
+    node = ControllerNode(model, over, seed=7)
+    assert node.run_once(0.1) is None          # gated on the first path message (dd:338)
+    node.set_path(px, py)
+    o = helpers.oracle_for(p)
+    s_n = np.zeros(p.nstate)
+    s_n[:2] = px[0], py[0]
+    s_o = s_n.copy()
+    for it in range(12):
+        dt = 0.1 if it % 3 else 0.093          # dt_ is the measured loop period (Q7)
+        node.set_state(s_n)
+        out = node.run_once(dt)
+        xr, yr, yaw = O_window(p, (px, py), s_o, dt)
+        u_o = o.iterate(s_o, dt, xr, yr, yaw[0], seed=7, rng="philox", iteration=it)
+        u_n = node.optimal_solution()
+        assert helpers.rel_err(u_n, u_o) < 1e-8
+        np.testing.assert_array_equal(node.ref_path()[:, 0], xr)
+        assert out["cmd_vel"] == (u_n[0, 0], u_n[0, 1])           # dd:250-251
+        o.set_nominal(u_n)
+        s_n = amd.plant_step(model, s_n, u_n[0], dt)
+        s_o = helpers.plant(model, s_o, u_n[0], dt)
+    # optimal path = the optimal controls re-rolled through the plant model (dd:295-312)
+    op = node.optimal_path()
+    node.set_state(s_n)
+    assert op.shape == (p.horizon - 1, 3)
+
+
+def O_window(p, path, state, dt):
+    from oracle import oracle_lib as O
+    _, xr, yr, yaw = O.calc_ref_path(path[0], path[1], state[0], state[1], p.v_ref, dt, p.resolution, p.horizon)
+    return xr, yr, yaw
+
+
+@pytest.mark.parametrize("model,kind,over", CASES)
+def test_stagewise_and_fused_nodes_agree(model, kind, over):
+    px, py = amd.make_path(kind)
+    a, b = ControllerNode(model, over, seed=3, fused=True), ControllerNode(model, over, seed=3, fused=False)
+    s = np.zeros(configs.NSTATE[model])
+    s[:2] = px[0], py[0] + 0.1
+    for n in (a, b):
+        n.set_path(px, py)
+    for it in range(4):
+        for n in (a, b):
+            n.set_state(s)
+        ra, rb = a.run_once(0.1), b.run_once(0.1)
+        np.testing.assert_array_equal(a.optimal_solution(), b.optimal_solution())
+        assert ra == rb
+        s = amd.plant_step(model, s, a.optimal_solution()[0], 0.1)
+
+
+def test_cmd_pos_post_processing():
+    tread = 0.501
+    px, py = amd.make_path("sinusoid")
+    # diff drive: steer 0, fore/rear = pitch_offset (dd:255-263)
+    n = ControllerNode("diff_drive", {"num_samples": 256, "horizon": 10})
+    n.set_path(px, py)
+    n.set_state([0.0, 0.0, 0.0])
+    out = n.run_once(0.1)
+    assert out["cmd_pos"] == (0.0, 0.0, 3.0 * DEG, 3.0 * DEG, 0.0)
+    # steering: inner/outer wheel angles (sd:275-291)
+    n = ControllerNode("steering_diff_drive", {"num_samples": 256, "horizon": 10})
+    n.set_path(px, py)
+    n.set_state([0.0, 0.0, 0.0])
+    out = n.run_once(0.1)
+    v, w, st = n.optimal_solution()[0]
+    R = abs(v / w)
+    s_in = np.arctan2(R * np.sin(st), R * np.cos(st) - tread / 2)
+    s_out = np.arctan2(R * np.sin(st), R * np.cos(st) + tread / 2)
+    want = (s_in, s_out) if w > 0 else (s_out, s_in)
+    np.testing.assert_allclose(out["cmd_pos"][:2], want, rtol=1e-14)
+    # full body: roll command = roll + roll_v*dt clamped to +-30 deg, zero when roll_off (fb:266-269)
+    n = ControllerNode("full_body", {"num_samples": 256, "horizon": 10})
+    n.set_path(px, py)
+    n.set_state([0.0, 0.0, 0.0, 29.9 * DEG, 0.0])
+    out = n.run_once(0.1)
+    rv = n.optimal_solution()[0, 3]
+    assert abs(out["cmd_pos"][4] - min(max(29.9 * DEG + rv * 0.1, -30 * DEG), 30 * DEG)) < 1e-15
+    n = ControllerNode("full_body", {"num_samples": 256, "horizon": 10, "roll_off": 1, "steer_off": 1})
+    n.set_path(px, py)
+    n.set_state([0.0, 0.0, 0.0, 0.1, 0.0])
+    out = n.run_once(0.1)
+    assert out["cmd_pos"][0] == 0.0 and out["cmd_pos"][1] == 0.0 and out["cmd_pos"][4] == 0.0
+    assert np.all(n.optimal_solution()[:, 2] == 0.0)            # steer_off zeroes the direction samples (fb:517)
