@@ -133,7 +133,9 @@ def main():
     ctl = amd.MPPIController(p, device=local_rank, num_samples=k_local, sample_offset=rank * k_local,
                              no_state_store=args.no_state_store)
     from ccv_mppi_path_tracker_amd import sharded
-    stream = torch.cuda.current_stream()
+    # a dedicated (non-default) stream: the legacy default stream adds implicit synchronisation to every launch
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     ctl.set_stream(stream.cuda_stream)
     inputs = script_inputs(amd, w, 64)
     seed = 42
