@@ -12,7 +12,11 @@
 #include <vector>
 
 #include "mppi_kernels.h"
+#if defined(CCV_USE_RR)
+#include "experimental/mppi_rollout_rr.h"   // A/B experiments only (tools/ablate.py)
+#else
 #include "mppi_rollout_pc.h"
+#endif
 
 using namespace ccv;
 

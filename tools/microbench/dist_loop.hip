@@ -116,11 +116,40 @@ __device__ __forceinline__ void v6(const double (&px)[TU], const double (&py)[TU
     }
 }
 
+// V7: plain fmin, 4 points per group, the NEXT group's coefficients are fetched from LDS while the current group is
+// evaluated (ping-pong register sets; the empty asm pins the current set so the loads cannot be re-materialised at use)
+#define PIN4(ab, c) asm volatile("" : "+v"(ab[0].x), "+v"(ab[0].y), "+v"(ab[1].x), "+v"(ab[1].y), "+v"(ab[2].x), "+v"(ab[2].y), \
+                                      "+v"(ab[3].x), "+v"(ab[3].y), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]))
+__device__ __forceinline__ void group4(const double (&px)[TU], const double (&py)[TU], double (&m)[TU], const double2 (&ab)[4], const double (&c)[4]) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int i = 0; i < TU; ++i) m[i] = fmin(m[i], fma(ab[jj].x, px[i], fma(ab[jj].y, py[i], c[jj])));
+}
+__device__ __forceinline__ void v7(const double (&px)[TU], const double (&py)[TU], double (&m)[TU], int H, const double2* sab, const double* sc, const Win&) {
+    const int H4 = (H + 3) & ~3;   // caller's arrays are padded
+    double2 a0[4], a1[4]; double c0[4], c1[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) { a0[jj] = sab[jj]; c0[jj] = sc[jj]; }
+    for (int j = 0; j < H4; j += 8) {
+        const int j1 = (j + 4 < H4) ? j + 4 : j;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { a1[jj] = sab[j1 + jj]; c1[jj] = sc[j1 + jj]; }
+        PIN4(a0, c0);
+        group4(px, py, m, a0, c0);
+        const int j2 = (j + 8 < H4) ? j + 8 : j1;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { a0[jj] = sab[j2 + jj]; c0[jj] = sc[j2 + jj]; }
+        PIN4(a1, c1);
+        if (j + 4 < H4) group4(px, py, m, a1, c1);
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void k(double* out, int H, unsigned long long* cyc, const Win W) {
     __shared__ double2 sab[MAXH];
     __shared__ double sc[MAXH];
-    for (int j = threadIdx.x; j < H + 2; j += 256) { sab[j] = make_double2(W.a[j], W.b[j]); sc[j] = W.c[j]; }
+    for (int j = threadIdx.x; j < H + 8; j += 256) { sab[j] = make_double2(W.a[j], W.b[j]); sc[j] = W.c[j]; }
     __syncthreads();
     double px[TU], py[TU], m[TU];
 #pragma unroll
@@ -132,6 +161,7 @@ __global__ __launch_bounds__(256) void k(double* out, int H, unsigned long long*
         else if (V == 2) v2(px, py, m, H, sab, sc, W);
         else if (V == 3) v3(px, py, m, H, sab, sc, W);
         else if (V == 5) v5(px, py, m, H, sab, sc, W);
+        else if (V == 7) v7(px, py, m, H, sab, sc, W);
         else if (V == 6) v6(px, py, m, H, sab, sc, W);
         else v4(px, py, m, H, sab, sc, W);
 #pragma unroll
@@ -178,6 +208,7 @@ int main() {
         run<2>("V2 asm min, 2 pts/iter", wps, H, W);
         run<3>("V3 scalar loads", wps, H, W);
         run<5>("V5 asm block/pt", wps, H, W);
+        run<7>("V7 fmin, 4/grp, ping-pong", wps, H, W);
         run<6>("V6 asm block, 2 pts/iter", wps, H, W);
         printf("\n");
     }
