@@ -383,7 +383,7 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const PcShared<
     for (int i = 0; i < NV; ++i) {
         // d^2 = |p|^2 + min_j(...), gate d <= 100 (dd:185), cost += path_weight*d*d (dd:206)
         double d2 = m[i] + fma(px[i], px[i], py[i] * py[i]);
-        d2 = fmin(fmax(d2, 0.0), 1.0e4);
+        d2 = d2 < 1.0e4 ? fmax(d2, 0.0) : 1.0e4;   // NaN -> gate value, as `distance < min_distance` (dd:189) is false for NaN
         cost += A.w_path * d2;
     }
 }

@@ -284,6 +284,63 @@ def test_large_world_coordinates():
     assert helpers.rel_err(u_g, u_o) < 1e-8
 
 
+@pytest.mark.parametrize("model", ["diff_drive", "steering_diff_drive", "full_body"])
+def test_huge_heading_takes_the_libm_path(model):
+    """The production kernel's branch-free sin/cos is valid for |angle| <= 1e5; beyond that the host routes the call to
+    the plain kernel with OCML's sincos (ccv_mppi_capi.hip: fast_trig_safe).  Results must still match the oracle."""
+    mk = {"diff_drive": configs.diff_drive_defaults, "steering_diff_drive": configs.steering_defaults,
+          "full_body": configs.full_body_defaults}[model]
+    p = mk(192, 20).with_(yaw_weight=0.0)        # (the fb yaw term would be 2*(3e5)^2 and underflow every weight)
+    path = helpers.oracle_path("sinusoid")
+    state = np.zeros(p.nstate)
+    state[:3] = 0.3, -0.2, 3.0e5 + 0.4          # yaw far outside [-pi, pi]
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    u_o = o.iterate(state, p.dt, xr, yr, yaw[0], seed=6, rng="philox", iteration=2)
+    u_g, st = g.iterate(state, p.dt, xr, yr, yaw[0], 6, 2)
+    assert np.max(np.abs(g.read_costs() - o.costs()) / o.costs()) < TOL_COST
+    assert helpers.rel_err(u_g, u_o) < 1e-8
+    # the stage-wise path with injected, unbounded controls makes the same decision from the injected magnitudes
+    ctrl = o.get_controls().copy()
+    ctrl[5, 3, 1] = 4.0e6                       # one absurd yaw rate
+    o.set_controls(ctrl)
+    o.predict_States(state, p.dt)
+    o.calc_Weights(xr, yr, yaw[0])
+    g.inject_controls(ctrl)
+    g.predict_States(state, p.dt)
+    g.calc_Weights(xr, yr, yaw[0])
+    c_o, c_g = o.costs(), g.read_costs()
+    assert np.max(np.abs(c_g - c_o) / c_o) < TOL_COST
+
+
+def test_nan_pose_propagates_like_the_reference():
+    """No NaN guard anywhere in the reference: a NaN pose makes every cost, weight and control NaN."""
+    p = configs.diff_drive_defaults(128, 12)
+    path = helpers.oracle_path("straight")
+    state = np.array([0.0, 0.0, np.nan])
+    xr, yr, yaw = helpers.oracle_window(p, path, np.zeros(3))
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    u_o = o.iterate(state, p.dt, xr, yr, yaw[0], seed=1, rng="philox", iteration=0)
+    u_g, st = g.iterate(state, p.dt, xr, yr, yaw[0], 1, 0)
+    assert np.all(np.isnan(u_o)) and np.all(np.isnan(u_g)) and st.nonfinite == 1
+
+
+def test_nan_warm_start_stays_nan_like_the_reference():
+    """After an all-underflow iteration optimal_solution is NaN; the reference then draws N(NaN, sigma) forever."""
+    p = configs.workload("C2").params.with_(num_samples=256, horizon=20)
+    path = helpers.oracle_path("sinusoid")
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    nom = np.zeros((p.horizon - 1, p.udim))
+    nom[3, 0] = np.nan
+    o.set_nominal(nom)
+    g.set_nominal(nom)
+    u_o = o.iterate(state, p.dt, xr, yr, yaw[0], seed=1, rng="philox", iteration=0)
+    u_g, st = g.iterate(state, p.dt, xr, yr, yaw[0], 1, 0)
+    assert np.all(np.isnan(u_o)) and np.all(np.isnan(u_g)) and st.nonfinite == 1
+
+
 def test_read_back_ranges_and_errors():
     p = configs.workload("C2").params.with_(num_samples=300, horizon=12)
     path = helpers.oracle_path("sinusoid")
