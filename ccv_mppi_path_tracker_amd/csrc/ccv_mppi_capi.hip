@@ -437,7 +437,7 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
         if ((e = hipMemset(*a.p, 0, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipMemset", e);
     }
 #if defined(CCV_STAMP)
-    if ((e = hipMalloc(&h->d_dbg, (64 + 3 * 4096) * sizeof(unsigned long long))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
+    if ((e = hipMalloc(&h->d_dbg, (64 + 6 * 4096) * sizeof(unsigned long long))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
 #endif
     h->pin_doubles = (size_t)h->R + 16;
     if ((e = hipHostMalloc(&h->h_pin, h->pin_doubles * sizeof(double), hipHostMallocDefault)) != hipSuccess)
@@ -487,7 +487,7 @@ extern "C" int ccv_mppi_debug_stamps(ccv_mppi_handle* h, unsigned long long* out
 }
 extern "C" int ccv_mppi_debug_blocks(ccv_mppi_handle* h, unsigned long long* out, int nblocks) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(out, h->d_dbg + 64, (size_t)nblocks * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out, h->d_dbg + 64, (size_t)nblocks * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CCV_MPPI_OK;
 }
 #endif

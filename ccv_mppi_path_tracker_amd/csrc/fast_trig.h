@@ -9,6 +9,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "noise_spec.h"   // CCV_KEEP_ORDER
+
 namespace ccv {
 
 constexpr double kFastTrigLimit = 1.0e5;
@@ -43,6 +45,57 @@ __device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
     const double ca = (q & 1) ? sr : cr;
     s = (q & 2) ? -sa : sa;
     c = ((q + 1) & 2) ? -ca : ca;
+}
+
+// N independent evaluations of fast_sincos, stage by stage: the same arithmetic per element, arranged so that the N
+// serial chains (reduction, two polynomials) interleave in program order.
+template <int N>
+__device__ __forceinline__ void fast_sincos_n(const double (&x)[N], double (&s)[N], double (&c)[N]) {
+    double fn[N], r[N], z[N], ps[N], pc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) fn[i] = __builtin_rint(x[i] * 6.36619772367581382433e-01);
+    CCV_KEEP_ORDER();
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fma(-fn[i], 1.57079632673412561417e+00, x[i]);
+    CCV_KEEP_ORDER();
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fma(-fn[i], 6.07710050630396597660e-11, r[i]);
+    CCV_KEEP_ORDER();
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fma(-fn[i], 2.02226624879595063154e-21, r[i]);
+    CCV_KEEP_ORDER();
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = r[i] * r[i];
+    CCV_KEEP_ORDER();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ps[i] = fma(z[i], 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+        pc[i] = fma(z[i], -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    }
+    CCV_KEEP_ORDER();
+#define CCV_STAGE2(cs_, cc_)                                         \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) {                  \
+        ps[i] = fma(z[i], ps[i], cs_);                               \
+        pc[i] = fma(z[i], pc[i], cc_);                               \
+    }                                                                \
+    CCV_KEEP_ORDER();
+    CCV_STAGE2(2.75573137070700676789e-06, -2.75573143513906633035e-07)
+    CCV_STAGE2(-1.98412698298579493134e-04, 2.48015872894767294178e-05)
+    CCV_STAGE2(8.33333333332248946124e-03, -1.38888888888741095749e-03)
+    CCV_STAGE2(-1.66666666666666324348e-01, 4.16666666666666019037e-02)
+#undef CCV_STAGE2
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double sr = fma(z[i] * r[i], ps[i], r[i]);
+        const double hz = 0.5 * z[i];
+        const double w = 1.0 - hz;
+        const double cr = w + (((1.0 - w) - hz) + z[i] * (z[i] * pc[i]));
+        const int q = (int)fn[i];
+        const double sa = (q & 1) ? cr : sr;
+        const double ca = (q & 1) ? sr : cr;
+        s[i] = (q & 2) ? -sa : sa;
+        c[i] = ((q + 1) & 2) ? -ca : ca;
+    }
 }
 
 }  // namespace ccv

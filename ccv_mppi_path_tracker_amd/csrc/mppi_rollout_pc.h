@@ -218,32 +218,60 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
     // ---- 1. controls of the 8 steps
     double u[kTU][UD];
     if constexpr (MODE == MODE_FUSED) {
-        static_for<NCALL>([&](auto CC) {
-            constexpr int c = decltype(CC)::value;
-            const int n0 = t0 * UD + 4 * c;
-            const double4 nom = *reinterpret_cast<const double4*>(A.nominal + n0);   // wave-uniform warm start u*[n0..n0+3]
-            float z[4];
+        // Philox blocks in groups of PG with their rounds interleaved, then the 2*PG Box-Muller pairs stage by stage
+        constexpr int PG = NCALL <= 4 ? NCALL : NCALL / 2;
+        static_assert(NCALL % PG == 0, "group size");
+        // warm start u*: wave-uniform, read-only for the lifetime of the kernel -> scalar loads (constant address space),
+        // which also keeps it off the vector-memory counter that the control stores occupy
+        typedef const double __attribute__((address_space(4))) kdouble;
+        const kdouble* nomk = (const kdouble*)A.nominal + t0 * UD;
+        static_for<NCALL / PG>([&](auto GG) {
+            constexpr int g = decltype(GG)::value;
+            float z[4 * PG];
 #if defined(CCV_ABL_NO_NOISE)
-            z[0] = z[1] = z[2] = z[3] = (float)(kg & 1023u) * 1e-3f - 0.5f;
+#pragma unroll
+            for (int i = 0; i < 4 * PG; ++i) z[i] = (float)(kg & 1023u) * 1e-3f - 0.5f;
 #else
-            const Philox4 r = philox4x32_10(kg, (uint32_t)(n0 >> 2), A.iter_lo, A.iter_hi, A.seed_lo, A.seed_hi);
-            box_muller_f32(r.x, r.y, z[0], z[1]);
-            box_muller_f32(r.z, r.w, z[2], z[3]);
+            uint32_t c0[PG], c1[PG], c2[PG], c3[PG];
+#pragma unroll
+            for (int i = 0; i < PG; ++i) {
+                c0[i] = kg;
+                c1[i] = (uint32_t)((t0 * UD) >> 2) + (uint32_t)(g * PG + i);
+                c2[i] = A.iter_lo;
+                c3[i] = A.iter_hi;
+            }
+            philox4x32_10_n<PG>(c0, c1, c2, c3, A.seed_lo, A.seed_hi);
+            uint32_t ba[2 * PG], bb[2 * PG];
+            float z0[2 * PG], z1[2 * PG];
+#pragma unroll
+            for (int i = 0; i < PG; ++i) {
+                ba[2 * i] = c0[i];
+                bb[2 * i] = c1[i];
+                ba[2 * i + 1] = c2[i];
+                bb[2 * i + 1] = c3[i];
+            }
+            box_muller_f32_n<2 * PG>(ba, bb, z0, z1);
+#pragma unroll
+            for (int i = 0; i < 2 * PG; ++i) {
+                z[2 * i] = z0[i];
+                z[2 * i + 1] = z1[i];
+            }
 #endif
-            const double mean[4] = {nom.x, nom.y, nom.z, nom.w};
-            static_for<4>([&](auto II) {
+            static_for<4 * PG>([&](auto II) {
                 constexpr int i = decltype(II)::value;
-                constexpr int nloc = 4 * c + i;
+                constexpr int nloc = 4 * g * PG + i;
                 constexpr int tt = nloc / UD, d = nloc % UD;
                 // libstdc++ normal_distribution: ret * stddev + mean (dd:96-97), then clamp (dd:98-99)
-                double v = (double)z[i] * A.sigma + mean[i];
+                double v = (double)z[i] * A.sigma + nomk[nloc];
                 v = clampd(v, arg5<d>(A.umin), arg5<d>(A.umax));
                 if constexpr (FB && d == 2) {
                     if (A.steer_off) v = 0.0;   // fb:517
                 }
                 u[tt][d] = v;
 #if !defined(CCV_ABL_NO_STORE)
-                if (live) A.u[(size_t)(n0 + i) * pitch + k] = v;
+                // no `live` predicate: rows are padded to a multiple of 64 samples (pitch), lanes past K write their
+                // padding slot -- a branch per store would cut this block into pieces the scheduler cannot interleave
+                A.u[(size_t)(t0 * UD + nloc) * pitch + k] = v;
 #endif
             });
         });
@@ -278,16 +306,28 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
         if constexpr (MODEL != CCV_MPPI_DIFF_DRIVE) hd[tt] = yawv[tt] + u[tt][2];
     }
     CCV_STAMP_AT(ST, 1);
-    // ---- 3. sin/cos of the 8 headings (independent chains)
+    // ---- 3. sin/cos of the 8 headings: independent chains, evaluated stage by stage in two groups of four
     double sn[kTU], cs[kTU];
-#pragma unroll
-    for (int tt = 0; tt < kTU; ++tt) {
 #if defined(CCV_ABL_NO_SINCOS)
-        sn[tt] = hd[tt] * 0.5; cs[tt] = 1.0 - hd[tt] * 0.25;
+#pragma unroll
+    for (int tt = 0; tt < kTU; ++tt) { sn[tt] = hd[tt] * 0.5; cs[tt] = 1.0 - hd[tt] * 0.25; }
 #else
-        fast_sincos(hd[tt], sn[tt], cs[tt]);
-#endif
+    {
+        constexpr int SG = 4;
+#pragma unroll
+        for (int g = 0; g < kTU / SG; ++g) {
+            double xin[SG], so[SG], co[SG];
+#pragma unroll
+            for (int i = 0; i < SG; ++i) xin[i] = hd[g * SG + i];
+            fast_sincos_n<SG>(xin, so, co);
+#pragma unroll
+            for (int i = 0; i < SG; ++i) {
+                sn[g * SG + i] = so[i];
+                cs[g * SG + i] = co[i];
+            }
+        }
     }
+#endif
     CCV_STAMP_AT(ST, 2);
     // ---- 4. cost terms that do not need the window
     if constexpr (COST) {
@@ -299,18 +339,25 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
 #pragma unroll
             for (int tt = 0; tt < kTU; ++tt) {
                 const int t = t0 + tt;
-                if (t < H - 2) {                                                      // fb:409
-                    cost += A.w_v * (u[tt][0] - A.v_ref) * (u[tt][0] - A.v_ref);      // fb:413
-                    if (u[tt][0] < 0.0) cost += A.w_back * u[tt][0] * u[tt][0];       // fb:420
+                // the two step-range conditions are wave-uniform: selects, not branches, keep the block in one piece
+                {                                                                     // fb:409: t < H - 2
+                    const double cv = A.w_v * (u[tt][0] - A.v_ref) * (u[tt][0] - A.v_ref);       // fb:413
+                    const double cb = A.w_back * u[tt][0] * u[tt][0];                            // fb:420
+                    const bool in = t < H - 2;
+                    cost += in ? cv : 0.0;
+                    cost += (in && u[tt][0] < 0.0) ? cb : 0.0;
                 }
-                if (t >= 1) {   // finish index t-1: ZMP (fb:468-485, 597-603) and roll-rate terms
+                {   // t >= 1: finish index t-1: ZMP (fb:468-485, 597-603) and roll-rate terms
                     const double drive_accel = (u[tt][0] - S.p_v) / dt;                          // fb:469
                     const double ay = drive_accel * S.p_sdir + S.p_ac * S.p_cdir;                // fb:473
                     const double hgdot_x = (A.fb_Ixx * u[tt][3] - A.fb_Ixx * S.p_rv) / dt;       // fb:479-481
                     const double mo_x = (S.p_c2 * mgz + S.p_c3 * (A.fb_mass * ay)) - hgdot_x;    // fb:600
                     const double zmp_y = mo_x / mgz;                                             // fb:601
-                    cost += A.w_zmp * zmp_y * zmp_y;                                             // fb:416
-                    cost += A.w_rollv * (u[tt][3] - S.p_rv) * (u[tt][3] - S.p_rv);               // fb:418
+                    const double cz = A.w_zmp * zmp_y * zmp_y;                                   // fb:416
+                    const double cr = A.w_rollv * (u[tt][3] - S.p_rv) * (u[tt][3] - S.p_rv);     // fb:418
+                    const bool in = t >= 1;
+                    cost += in ? cz : 0.0;
+                    cost += in ? cr : 0.0;
                 }
                 double sd_, cd_, sr_, cr_, sp_, cp_;
                 fast_sincos(u[tt][2], sd_, cd_);
@@ -328,20 +375,26 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
     }
     // ---- 5. positions (dd:106-107), hand-off of (x,y) - pose to the consumer, x,y -> HBM
     double x = S.x, y = S.y;
+    double xv[kTU], yv[kTU];
 #pragma unroll
     for (int tt = 0; tt < kTU; ++tt) {
+        xv[tt] = x;
+        yv[tt] = y;
         sh.p[b & 1][tt][0][lane] = x - A.x0[0];
         sh.p[b & 1][tt][1][lane] = y - A.x0[1];
-        if constexpr (MODE != MODE_COST) {
-#if !defined(CCV_ABL_NO_STORE)
-            if (A.store_xy && live) {
-                A.xs[(size_t)(t0 + tt) * pitch + k] = x;
-                A.ys[(size_t)(t0 + tt) * pitch + k] = y;
-            }
-#endif
-        }
         x = x + u[tt][0] * cs[tt] * dt;
         y = y + u[tt][0] * sn[tt] * dt;
+    }
+    if constexpr (MODE != MODE_COST) {
+#if !defined(CCV_ABL_NO_STORE)
+        if (A.store_xy) {   // one wave-uniform branch for the 16 stores (padded rows: no `live` predicate, as above)
+#pragma unroll
+            for (int tt = 0; tt < kTU; ++tt) {
+                A.xs[(size_t)(t0 + tt) * pitch + k] = xv[tt];
+                A.ys[(size_t)(t0 + tt) * pitch + k] = yv[tt];
+            }
+        }
+#endif
     }
     CCV_STAMP_AT(ST, 3);
     S.x = x;
@@ -370,14 +423,42 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const PcShared<
         py[i] = sh.p[b & 1][i][1][lane];
         m[i] = INFINITY;
     }
-    for (int j = 0; j < H4; j += 4) {
+    // software pipeline: the coefficients of points j+4..j+7 are read from LDS (broadcast reads) before the ~100 fp64
+    // instructions on points j..j+3 issue, so no iteration waits out the LDS latency.  sh.ab / sh.c carry 4 spare
+    // entries past H4, so the last iteration's read-ahead stays inside the arrays.
+    double2 ab0[4], ab1[4];
+    double c0[4], c1[4];
+    auto fetch = [&](double2(&ab)[4], double(&c)[4], const int j) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const double2 ab = sh.ab[j + jj];
-            const double c = sh.c[j + jj];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) m[i] = fmin(m[i], fma(ab.x, px[i], fma(ab.y, py[i], c)));
+            ab[jj] = sh.ab[j + jj];
+            c[jj] = sh.c[j + jj];
         }
+    };
+    auto points4 = [&](const double2(&ab)[4], const double(&c)[4]) {
+        double f[4][NV];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) f[jj][i] = fma(ab[jj].x, px[i], fma(ab[jj].y, py[i], c[jj]));
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            // the three minima over freshly computed values need no canonicalising v_max; the loop-carried one would get
+            // one per iteration from the compiler (it cannot see through the phi that m is already quiet), so it is
+            // issued directly: v_min_f64 of two quiet operands
+            const double t = fmin(fmin(f[0][i], f[1][i]), fmin(f[2][i], f[3][i]));
+            asm("v_min_f64 %0, %1, %2" : "=v"(m[i]) : "v"(m[i]), "v"(t));
+        }
+    };
+    fetch(ab0, c0, 0);
+    for (int j = 0; j < H4; j += 8) {   // two register sets in ping-pong: no copies
+        fetch(ab1, c1, j + 4);
+        __builtin_amdgcn_sched_barrier(0);   // keep the read-ahead above the arithmetic (the scheduler would sink it)
+        points4(ab0, c0);
+        if (j + 4 >= H4) break;
+        fetch(ab0, c0, j + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        points4(ab1, c1);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -437,7 +518,7 @@ __device__ __forceinline__ void pc_partial_update(const RolloutArgs& A, PcShared
 }
 
 template <int MODEL, int MODE>
-__global__ __launch_bounds__(kPcWaves * 64, 4) void k_rollout_pc(const RolloutArgs A, const Window W) {
+__global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutArgs A, const Window W) {
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     constexpr bool COST = MODE != MODE_ROLLOUT;
     __shared__ PcShared<MODEL> sh;
@@ -559,13 +640,14 @@ __global__ __launch_bounds__(kPcWaves * 64, 4) void k_rollout_pc(const RolloutAr
     if (A.dbg && lane == 0 && blockIdx.x == 3) {
         for (int i = 0; i < 8; ++i) A.dbg[wv * 8 + i] = ST.acc[i];
     }
-    if (A.dbg && lane == 0 && wv == 0 && blockIdx.x < 4096) {
+    if (A.dbg && lane == 0 && blockIdx.x < 4096) {
+        // per block: [start, loop end wave 0, hw id wave 0, loop end wave 1, hw id wave 1, kernel end wave 0]
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         unsigned int hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
         unsigned int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
-        A.dbg[64 + blockIdx.x * 3 + 0] = rt0;
-        A.dbg[64 + blockIdx.x * 3 + 1] = rt1;
-        A.dbg[64 + blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid;
+        if (wv == 0) A.dbg[64 + blockIdx.x * 6 + 0] = rt0;
+        A.dbg[64 + blockIdx.x * 6 + 1 + 2 * wv] = rt1;
+        A.dbg[64 + blockIdx.x * 6 + 2 + 2 * wv] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
     if constexpr (COST) {
@@ -579,6 +661,12 @@ __global__ __launch_bounds__(kPcWaves * 64, 4) void k_rollout_pc(const RolloutAr
         }
         if (A.fuse_update) pc_partial_update<MODEL>(A, sh, wgt, total, lane, wv, kk, live);
     }
+#if defined(CCV_STAMP)
+    if (A.dbg && lane == 0 && wv == 0 && blockIdx.x < 4096) {
+        __builtin_amdgcn_s_waitcnt(0);
+        A.dbg[64 + blockIdx.x * 6 + 5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 }  // namespace ccv

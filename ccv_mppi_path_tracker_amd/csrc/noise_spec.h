@@ -18,6 +18,10 @@
 
 namespace ccv {
 
+// The machine scheduler re-serialises interleaved chains to save registers; a scheduling barrier between the stages of
+// the N-wide helpers keeps the stage order (nothing else is affected: it emits no instruction).
+#define CCV_KEEP_ORDER() __builtin_amdgcn_sched_barrier(0)
+
 struct Philox4 {
     uint32_t x, y, z, w;
 };
@@ -39,6 +43,35 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
         k1 += 0xBB67AE85u;
     }
     return Philox4{c0, c1, c2, c3};
+}
+
+// N independent Philox blocks with the rounds interleaved (round r of every block before round r+1 of any): the same
+// arithmetic as philox4x32_10 per block, written in the order a lone wave should issue it -- the multiplies of the N
+// blocks are independent, so their latencies overlap instead of adding up.  The compiler keeps this order.
+template <int N>
+__device__ __forceinline__ void philox4x32_10_n(uint32_t (&c0)[N], uint32_t (&c1)[N], uint32_t (&c2)[N], uint32_t (&c3)[N],
+                                                uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long pa[N], pb[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            pa[i] = (unsigned long long)c0[i] * 0xD2511F53ull;
+            pb[i] = (unsigned long long)c2[i] * 0xCD9E8D57ull;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const uint32_t n0 = (uint32_t)(pb[i] >> 32) ^ c1[i] ^ k0;
+            const uint32_t n2 = (uint32_t)(pa[i] >> 32) ^ c3[i] ^ k1;
+            c1[i] = (uint32_t)pb[i];
+            c3[i] = (uint32_t)pa[i];
+            c0[i] = n0;
+            c2[i] = n2;
+        }
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+        CCV_KEEP_ORDER();
+    }
 }
 
 // -log2 polynomial, sin/cos polynomials: tools/fit_normal_polys.py
@@ -94,6 +127,66 @@ __device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& z0
     const float sq = (quad >= 2u) ? -sa : sa;
     z0 = r * cq;
     z1 = r * sq;
+}
+
+// N independent Box-Muller pairs, stage by stage (the same per-element arithmetic as box_muller_f32, bit for bit): the
+// two serial polynomial chains of every pair advance together, N-way instruction-level parallelism for a lone wave.
+template <int N>
+__device__ __forceinline__ void box_muller_f32_n(const uint32_t (&a)[N], const uint32_t (&b)[N], float (&z0)[N], float (&z1)[N]) {
+    float t[N], L0[N], q[N], al[N], w[N], s[N], c[N], r[N];
+    uint32_t quad[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t a1 = a[i] == 0u ? 1u : a[i];
+        const int lz = __builtin_clz(a1);
+        const uint32_t m = a1 << lz;
+        const bool fold = m > 0xB504F333u;
+        t[i] = fold ? -((float)(0u - m) * 0x1p-32f) : (float)(m - 0x80000000u) * 0x1p-31f;
+        L0[i] = (float)(1 + lz - (fold ? 1 : 0));
+        quad[i] = b[i] >> 30;
+        const int32_t f = (int32_t)(b[i] & 0x3FFFFFFFu) - (1 << 29);
+        al[i] = (float)f * 0x1.921fb6p-30f;
+        w[i] = al[i] * al[i];
+        q[i] = CCV_Q8;
+        s[i] = 0x1.6dbc3ep-19f;
+        c[i] = 0x1.9a6a98p-16f;
+    }
+    CCV_KEEP_ORDER();
+#define CCV_STAGE(var, x, coef)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) var[i] = __builtin_fmaf(var[i], x[i], coef); \
+    CCV_KEEP_ORDER();
+    CCV_STAGE(q, t, CCV_Q7)
+    CCV_STAGE(s, w, -0x1.a013a2p-13f)
+    CCV_STAGE(c, w, -0x1.6c0df8p-10f)
+    CCV_STAGE(q, t, CCV_Q6)
+    CCV_STAGE(s, w, 0x1.11110ep-7f)
+    CCV_STAGE(c, w, 0x1.55554cp-5f)
+    CCV_STAGE(q, t, CCV_Q5)
+    CCV_STAGE(s, w, -0x1.555556p-3f)
+    CCV_STAGE(c, w, -0x1.000000p-1f)
+    CCV_STAGE(q, t, CCV_Q4)
+    CCV_STAGE(q, t, CCV_Q3)
+    CCV_STAGE(q, t, CCV_Q2)
+    CCV_STAGE(q, t, CCV_Q1)
+    CCV_STAGE(q, t, CCV_Q0)
+#undef CCV_STAGE
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float L = __builtin_fmaf(-t[i], q[i], L0[i]);
+        r[i] = __builtin_sqrtf(L * 0x1.62e430p+0f);
+    }
+    CCV_KEEP_ORDER();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float sn = __builtin_fmaf(al[i] * w[i], s[i], al[i]);
+        const float cs = __builtin_fmaf(w[i], c[i], 1.0f);
+        const float ca = (quad[i] & 1u) ? sn : cs;
+        const float sa = (quad[i] & 1u) ? cs : sn;
+        const float cq = (quad[i] == 1u || quad[i] == 2u) ? -ca : ca;
+        const float sq = (quad[i] >= 2u) ? -sa : sa;
+        z0[i] = r[i] * cq;
+        z1[i] = r[i] * sq;
+    }
 }
 
 }  // namespace ccv

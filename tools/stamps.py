@@ -22,6 +22,10 @@ _, xr, yr, yaw = amd.calc_ref_path(px, py, 0.0, 0.0, p.v_ref, p.dt, p.resolution
 g = amd.MPPIController(p)
 for it in range(5):
     g.iterate(s, p.dt, xr, yr, yaw[0], 1, it)
+NB2B = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # back-to-back launches before the read-out (steady-state clock)
+for it in range(NB2B):
+    g.iterate_enqueue(s, p.dt, xr, yr, yaw[0], 1, 5 + it)
+g.synchronize()
 out = (C.c_ulonglong * 32)()
 g.lib.ccv_mppi_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 g.lib.ccv_mppi_debug_stamps(g._h, out)
@@ -37,28 +41,48 @@ for i, n in enumerate(names):
 print("total    " + "  ".join("%8.0f" % v for v in a.sum(axis=1)))
 
 nb = min(4096, (K + 63) // 64)
-blk = (C.c_ulonglong * (3 * nb))()
+blk = (C.c_ulonglong * (6 * nb))()
 g.lib.ccv_mppi_debug_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 g.lib.ccv_mppi_debug_blocks(g._h, blk, nb)
-b = np.array(list(blk), dtype=np.uint64).reshape(nb, 3)
-t0 = b[:, 0].astype(np.float64); t1 = b[:, 1].astype(np.float64)
+b = np.array(list(blk), dtype=np.uint64).reshape(nb, 6)
+t0 = b[:, 0].astype(np.float64)
 base = t0.min()
-start_us = (t0 - base) / 100.0; end_us = (t1 - base) / 100.0     # s_memrealtime: 100 MHz
-hw = (b[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64); xcc = (b[:, 2] >> np.uint64(32)).astype(np.int64)
-cu = (hw >> 8) & 0xF; sh_ = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 0x3
-print("blocks %d: start min/median/max %.1f/%.1f/%.1f us, end min/median/max %.1f/%.1f/%.1f us, duration median %.1f us"
-      % (nb, start_us.min(), np.median(start_us), start_us.max(), end_us.min(), np.median(end_us), end_us.max(),
-         np.median(end_us - start_us)))
-hist, edges = np.histogram(start_us, bins=12)
-print("start-time histogram:", list(hist), " edges(us):", [round(e, 1) for e in edges])
-key = xcc * 10000 + se * 1000 + sh_ * 100 + cu
-uniq, counts = np.unique(key, return_counts=True)
-print("distinct (xcc,se,sh,cu): %d; blocks per CU min/max: %d/%d; xcc histogram: %s" % (len(uniq), counts.min(), counts.max(),
-      list(np.bincount(xcc, minlength=8))))
+start_us = (t0 - base) / 100.0                                   # s_memrealtime: 100 MHz
+end0_us = (b[:, 1].astype(np.float64) - base) / 100.0            # loop end, wave 0 / wave 1; kernel end (after the epilogue)
+end1_us = (b[:, 3].astype(np.float64) - base) / 100.0
+fin_us = (b[:, 5].astype(np.float64) - base) / 100.0
+end_us = np.maximum(end0_us, end1_us)
+
+
+def decode(word):
+    hw = (word & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    return dict(xcc=(word >> np.uint64(32)).astype(np.int64), cu=(hw >> 8) & 0xF, sh=(hw >> 12) & 0x1, se=(hw >> 13) & 0x7,
+                simd=(hw >> 4) & 0x3, wave=hw & 0xF)
+
+
+h0, h1 = decode(b[:, 2]), decode(b[:, 4])
+xcc = h0["xcc"]
 dur = end_us - start_us
-for x in range(8):
-    sel = xcc == x
-    print("xcc %d: blocks %d  end median %.1f max %.1f  duration median %.1f" % (x, sel.sum(), np.median(end_us[sel]), end_us[sel].max(), np.median(dur[sel])))
-order = np.argsort(end_us)
-print("slowest 8 blocks (id, xcc, se, cu, end):", [(int(i), int(xcc[i]), int(se[i]), int(cu[i]), round(float(end_us[i]), 1)) for i in order[-8:]])
-print("fastest 8 blocks:", [(int(i), int(xcc[i]), int(se[i]), int(cu[i]), round(float(end_us[i]), 1)) for i in order[:8]])
+print("blocks %d: start max %.1f us; loop end min/median/max %.1f/%.1f/%.1f us; kernel end median/max %.1f/%.1f us; "
+      "epilogue median %.1f us" % (nb, start_us.max(), end_us.min(), np.median(end_us), end_us.max(), np.median(fin_us),
+                                   fin_us.max(), np.median(fin_us - end0_us)))
+d3 = float(end0_us[3] - start_us[3])
+print("block 3: %.1f us by s_memrealtime, %.0f s_memtime ticks in the loop => shader clock >= %.2f GHz"
+      % (d3, a[0].sum(), a[0].sum() / d3 / 1e3))
+print("loop duration histogram:", np.histogram(dur, bins=10))
+# SIMD placement: how many waves of the kernel share a SIMD with this block's waves?
+cuid = xcc * 1000 + h0["se"] * 100 + h0["sh"] * 50 + h0["cu"]
+simd_key0 = cuid * 4 + h0["simd"]
+simd_key1 = cuid * 4 + h1["simd"]
+allk = np.concatenate([simd_key0, simd_key1])
+uk, cnt = np.unique(allk, return_counts=True)
+print("waves per SIMD histogram (over %d SIMDs used):" % len(uk), np.bincount(cnt))
+load = dict(zip(uk.tolist(), cnt.tolist()))
+l0 = np.array([load[k] for k in simd_key0.tolist()]); l1 = np.array([load[k] for k in simd_key1.tolist()])
+same = (h0["simd"] == h1["simd"])
+print("blocks whose two waves share a SIMD: %d" % same.sum())
+for lo in sorted(set((np.maximum(l0, l1)).tolist())):
+    sel = np.maximum(l0, l1) == lo
+    print("max waves on a SIMD used by the block = %d: %d blocks, loop duration median %.1f us" % (lo, sel.sum(), np.median(dur[sel])))
+print("same-SIMD blocks: median %.1f; split blocks: median %.1f" % (np.median(dur[same]) if same.any() else -1,
+                                                                   np.median(dur[~same]) if (~same).any() else -1))
