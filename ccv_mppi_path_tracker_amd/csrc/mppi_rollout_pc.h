@@ -69,6 +69,19 @@ struct PcShared {
     double cost[kPcWaves][kPcSamples];
 };
 
+// The candidate states x, y are written once and not read again by this kernel: streaming (non-temporal) stores keep
+// them from displacing the controls, which the epilogue re-reads, from L2 and from piling up as dirty lines that the
+// end-of-kernel write-back has to drain.
+#if defined(CCV_EXP_PLAIN_STATE_STORE)
+#define CCV_STATE_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define CCV_STATE_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
+
+// Workgroup barrier for the block hand-off.  The two waves exchange data through LDS only, so the barrier waits for LDS
+// (lgkmcnt) and not, as __syncthreads() does, for the acknowledgement of every control / state store still in flight.
+__device__ __forceinline__ void pc_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------------------------------------------------------
 // producer: steps t0 .. t0+7 of one sample (sampling + predict_NextState + control costs).  FULL: every step of the
 // block carries controls (t0 + 8 <= H - 1), so the body is branch-free.
@@ -95,8 +108,8 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, PcShared<MODEL>
             if constexpr (MODE != MODE_COST) {
 #if !defined(CCV_ABL_NO_STORE)
                 if (A.store_xy && live) {
-                    A.xs[(size_t)t * pitch + k] = S.x;
-                    A.ys[(size_t)t * pitch + k] = S.y;
+                    CCV_STATE_STORE(&A.xs[(size_t)t * pitch + k], S.x);
+                    CCV_STATE_STORE(&A.ys[(size_t)t * pitch + k], S.y);
                 }
 #endif
             }
@@ -390,8 +403,8 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
         if (A.store_xy) {   // one wave-uniform branch for the 16 stores (padded rows: no `live` predicate, as above)
 #pragma unroll
             for (int tt = 0; tt < kTU; ++tt) {
-                A.xs[(size_t)(t0 + tt) * pitch + k] = xv[tt];
-                A.ys[(size_t)(t0 + tt) * pitch + k] = yv[tt];
+                CCV_STATE_STORE(&A.xs[(size_t)(t0 + tt) * pitch + k], xv[tt]);
+                CCV_STATE_STORE(&A.ys[(size_t)(t0 + tt) * pitch + k], yv[tt]);
             }
         }
 #endif
@@ -476,31 +489,68 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const PcShared<
 // Rows are dealt to the two waves; a wave reduces 15 rows at a time through LDS: every lane drops w*u for each row,
 // then lane (r, q) adds 16 of the 64 entries of row r and two shuffles finish the row.  Fixed order => reproducible.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kUpdRB = 15;                  // rows per LDS batch: 15 * 65 doubles fit one wave's half of sh.p
+constexpr int kUpdCH = 4 * kUpdRB;          // rows whose loads are in flight together (120 VGPRs)
+
+// Control rows are dealt to the wave that produced (stored) them: wave w owns the time blocks s = w, w+2, ... so a wave
+// only re-reads its own stores (program order makes them visible; no vector-memory wait at the block barriers).
+// m = 0 .. count-1 enumerates a wave's rows.
 template <int MODEL>
-__device__ __forceinline__ void pc_partial_update(const RolloutArgs& A, PcShared<MODEL>& sh, const double wgt, const double total,
-                                                  const int lane, const int wv, const int kk, const bool live) {
+struct UpdRows {
+    static constexpr int BR = kTU * udim_of(MODEL);   // control rows per time block
+    int R, wv;
+    __device__ __forceinline__ int count() const {
+        int n = 0;
+        for (int r0 = wv * BR; r0 < R; r0 += 2 * BR) n += min(BR, R - r0);
+        return n;
+    }
+    __device__ __forceinline__ int row(const int m) const { return ((m / BR) * 2 + wv) * BR + m % BR; }
+};
+
+// The re-read of this workgroup's controls: the loads of a whole chunk of rows are issued back to back, so the chunk
+// pays one memory latency, not one per batch.  Rows past the end are clamped (loaded, never used).
+template <int MODEL>
+__device__ __forceinline__ void pc_update_fetch(const RolloutArgs& A, double (&v)[kUpdCH], const UpdRows<MODEL>& rows, const int m0,
+                                                const int mcount, const int kk) {
+    const size_t pitch = (size_t)A.pitch;
+#pragma unroll
+    for (int i = 0; i < kUpdCH; ++i) v[i] = A.u[(size_t)rows.row(min(m0 + i, mcount - 1)) * pitch + kk];
+}
+
+template <int MODEL>
+__device__ __forceinline__ void pc_partial_update(const RolloutArgs& A, PcShared<MODEL>& sh, double (&v)[kUpdCH],
+                                                  const UpdRows<MODEL>& rows, const int mcount, const double wgt,
+                                                  const double total, const int lane, const int wv, const int kk,
+                                                  const bool live) {
     constexpr int UD = udim_of(MODEL);
-    constexpr int RB = 15;                 // rows per batch: 15 * 65 doubles fit this wave's half of sh.p
+    constexpr int RB = kUpdRB;
     constexpr int STRIDE = kPcSamples + 1; // padded row: lanes (r, q) hit different banks
     const int R = (A.H - 1) * UD;
-    const size_t pitch = (size_t)A.pitch;
     double* buf = &sh.p[wv][0][0][0];      // 8 * 2 * 64 = 1024 doubles per wave, free after the last consume
     const int rr = lane >> 2, q = lane & 3;
-    __syncthreads();                       // everyone is done with sh.p
-    for (int base = wv * RB; base < R; base += kPcWaves * RB) {
-        const int nrows = min(RB, R - base);
-        for (int r = 0; r < nrows; ++r) buf[r * STRIDE + lane] = wgt * A.u[(size_t)(base + r) * pitch + kk];
-        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed (wave-private buffer)
-        __builtin_amdgcn_wave_barrier();
-        double acc = 0.0;
-        if (rr < nrows) {
+    // (the caller has fetched the first chunk into v and passed the barrier that frees sh.p)
+    for (int chunk0 = 0; chunk0 < mcount; chunk0 += kUpdCH) {
+        if (chunk0 != 0) pc_update_fetch<MODEL>(A, v, rows, chunk0, mcount, kk);
+        static_for<kUpdCH / RB>([&](auto BB) {
+            constexpr int bb = decltype(BB)::value;
+            const int base = chunk0 + bb * RB;
+            const int nrows = min(RB, mcount - base);
+            if (nrows > 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc += buf[rr * STRIDE + q * 16 + i];
-        }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        if (rr < nrows && q == 0) A.partial[(size_t)(base + rr) * A.nparts + blockIdx.x] = acc;
-        __builtin_amdgcn_wave_barrier();
+                for (int r = 0; r < RB; ++r) buf[r * STRIDE + lane] = wgt * v[bb * RB + r];
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed (wave-private buffer)
+                __builtin_amdgcn_wave_barrier();
+                double acc = 0.0;
+                if (rr < nrows) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc += buf[rr * STRIDE + q * 16 + i];
+                }
+                acc += __shfl_xor(acc, 1, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                if (rr < nrows && q == 0) A.partial[(size_t)rows.row(base + rr) * A.nparts + blockIdx.x] = acc;
+                __builtin_amdgcn_wave_barrier();
+            }
+        });
     }
     if (wv == 0) {
         // sum of weights + cost statistics of this workgroup
@@ -633,7 +683,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
                 CCV_STAMP_AT(ST, 5);
             }
         }
-        __syncthreads();
+        pc_barrier_lds();
         CCV_STAMP_AT(ST, 6);
     }
 #if defined(CCV_STAMP)
@@ -651,15 +701,20 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
     }
 #endif
     if constexpr (COST) {
+        double upd[kUpdCH];
+        const UpdRows<MODEL> rows{(H - 1) * udim_of(MODEL), wv};
+        const int mcount = A.fuse_update ? rows.count() : 0;
+        // start the re-read of this wave's controls before anything else (see pc_update_fetch)
+        if (mcount > 0) pc_update_fetch<MODEL>(A, upd, rows, 0, mcount, kk);
         sh.cost[wv][lane] = cost;
-        __syncthreads();
+        pc_barrier_lds();   // also: everyone is done with sh.p
         const double total = sh.cost[0][lane] + sh.cost[1][lane];
         const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
         if (wv == 0 && live) {
             A.cost[k] = total;
             A.w[k] = wgt;
         }
-        if (A.fuse_update) pc_partial_update<MODEL>(A, sh, wgt, total, lane, wv, kk, live);
+        if (A.fuse_update) pc_partial_update<MODEL>(A, sh, upd, rows, mcount, wgt, total, lane, wv, kk, live);
     }
 #if defined(CCV_STAMP)
     if (A.dbg && lane == 0 && wv == 0 && blockIdx.x < 4096) {
