@@ -86,3 +86,8 @@ for lo in sorted(set((np.maximum(l0, l1)).tolist())):
     print("max waves on a SIMD used by the block = %d: %d blocks, loop duration median %.1f us" % (lo, sel.sum(), np.median(dur[sel])))
 print("same-SIMD blocks: median %.1f; split blocks: median %.1f" % (np.median(dur[same]) if same.any() else -1,
                                                                    np.median(dur[~same]) if (~same).any() else -1))
+ep = fin_us - end0_us
+print("epilogue (kernel end - loop end, wave 0) histogram:", np.histogram(ep, bins=10))
+order = np.argsort(fin_us)
+print("last 6 blocks to end: ", [(int(i), round(float(end0_us[i]), 1), round(float(fin_us[i]), 1)) for i in order[-6:]])
+
