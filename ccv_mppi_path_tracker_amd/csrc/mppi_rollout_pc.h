@@ -62,12 +62,24 @@ constexpr int kPcStateWords = MODEL == CCV_MPPI_FULL_BODY ? 12 : 3;
 
 template <int MODEL>
 struct PcShared {
+    // kStage: the producer hands its controls and states to a store wave through LDS instead of storing them itself
+    // (mppi_rollout_r3.h); here it stores them to HBM directly
+    static constexpr bool kStage = false;
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
     double c[kMaxH + 4];
     double p[2][kTU][2][kPcSamples];                       // (x,y) - pose of the 8 states of a block, double buffered
     double st[2][kPcStateWords<MODEL>][kPcSamples];        // producer -> next producer
     double cost[kPcWaves][kPcSamples];
+    alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u* (see pc_stage_nominal)
 };
+
+// The warm start u* is staged in LDS once per workgroup.  Read straight from memory inside the time loop (scalar or
+// vector loads) every block of 8 steps exposes one cache-miss latency -- ~1500 cycles, measured -- on the producer chain.
+template <int MODEL, class SH>
+__device__ __forceinline__ void pc_stage_nominal(const RolloutArgs& A, SH& sh, const int nthreads) {
+    const int R = (A.H - 1) * udim_of(MODEL);
+    for (int j = threadIdx.x; j < R + 8; j += nthreads) sh.nom[j] = j < R ? A.nominal[j] : 0.0;
+}
 
 // The candidate states x, y are written once and not read again by this kernel: streaming (non-temporal) stores keep
 // them from displacing the controls, which the epilogue re-reads, from L2 and from piling up as dirty lines that the
@@ -86,8 +98,8 @@ __device__ __forceinline__ void pc_barrier_lds() { asm volatile("s_waitcnt lgkmc
 // producer: steps t0 .. t0+7 of one sample (sampling + predict_NextState + control costs).  FULL: every step of the
 // block carries controls (t0 + 8 <= H - 1), so the body is branch-free.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODEL, int MODE, bool FULL>
-__device__ __forceinline__ void pc_produce(const RolloutArgs& A, PcShared<MODEL>& sh, PcState<MODEL>& S, double& cost,
+template <int MODEL, int MODE, bool FULL, class SH>
+__device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState<MODEL>& S, double& cost,
                                            const int b, const int lane, const int k, const int kk, const bool live,
                                            const uint32_t kg) {
     constexpr int UD = udim_of(MODEL);
@@ -102,10 +114,15 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, PcShared<MODEL>
     static_for<kTU>([&](auto TT) {
         constexpr int tt = decltype(TT)::value;
         const int t = t0 + tt;
-        sh.p[b & 1][tt][0][lane] = S.x - A.x0[0];
-        sh.p[b & 1][tt][1][lane] = S.y - A.x0[1];
+        if constexpr (SH::kStage) {   // absolute: the store wave writes them out, the distance wave subtracts the pose
+            sh.p[b & 1][tt][0][lane] = S.x;
+            sh.p[b & 1][tt][1][lane] = S.y;
+        } else {
+            sh.p[b & 1][tt][0][lane] = S.x - A.x0[0];
+            sh.p[b & 1][tt][1][lane] = S.y - A.x0[1];
+        }
         if (FULL || t < H) {
-            if constexpr (MODE != MODE_COST) {
+            if constexpr (MODE != MODE_COST && !SH::kStage) {
 #if !defined(CCV_ABL_NO_STORE)
                 if (A.store_xy && live) {
                     CCV_STATE_STORE(&A.xs[(size_t)t * pitch + k], S.x);
@@ -122,7 +139,7 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, PcShared<MODEL>
                     if constexpr (MODE == MODE_FUSED) {
                         if constexpr ((nloc & 3) == 0) {
                             // warm start u*[n .. n+3]: wave-uniform load, in flight while the Philox rounds run
-                            nom = *reinterpret_cast<const double4*>(A.nominal + n);
+                            nom = *reinterpret_cast<const double4*>(&sh.nom[n]);
 #if defined(CCV_ABL_NO_NOISE)
                             zq[0] = zq[1] = zq[2] = zq[3] = (float)(kg & 1023u) * 1e-3f - 0.5f;
 #else
@@ -140,9 +157,13 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, PcShared<MODEL>
                             if (A.steer_off) v = 0.0;   // fb:517
                         }
                         u[d] = v;
+                        if constexpr (SH::kStage) {
+                            sh.us[b & 1][nloc][lane] = v;
+                        } else {
 #if !defined(CCV_ABL_NO_STORE)
-                        if (live) A.u[(size_t)n * pitch + k] = v;
+                            if (live) A.u[(size_t)n * pitch + k] = v;
 #endif
+                        }
                     } else {
                         u[d] = A.u[(size_t)n * pitch + kk];
                     }
@@ -212,8 +233,8 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, PcShared<MODEL>
 // batches so that the independent chains of the 8 steps (Philox rounds, Box-Muller, sin/cos) sit in ONE basic block and
 // interleave -- a lone wave then issues back to back instead of waiting out each chain's latency.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODEL, int MODE>
-__device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShared<MODEL>& sh, PcState<MODEL>& S, double& cost,
+template <int MODEL, int MODE, class SH>
+__device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh, PcState<MODEL>& S, double& cost,
                                                    const int b, const int lane, const int k, const int kk, const bool live,
                                                    const uint32_t kg
 #if defined(CCV_STAMP)
@@ -234,13 +255,13 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
         // Philox blocks in groups of PG with their rounds interleaved, then the 2*PG Box-Muller pairs stage by stage
         constexpr int PG = NCALL <= 4 ? NCALL : NCALL / 2;
         static_assert(NCALL % PG == 0, "group size");
-        // warm start u*: wave-uniform, read-only for the lifetime of the kernel -> scalar loads (constant address space),
-        // which also keeps it off the vector-memory counter that the control stores occupy
-        typedef const double __attribute__((address_space(4))) kdouble;
-        const kdouble* nomk = (const kdouble*)A.nominal + t0 * UD;
         static_for<NCALL / PG>([&](auto GG) {
             constexpr int g = decltype(GG)::value;
             float z[4 * PG];
+            double nomv[4 * PG];   // warm start u* of this group from LDS (broadcast reads), in flight under the Philox rounds
+#pragma unroll
+            for (int i = 0; i < 4 * PG; ++i) nomv[i] = sh.nom[t0 * UD + 4 * g * PG + i];
+            CCV_KEEP_ORDER();
 #if defined(CCV_ABL_NO_NOISE)
 #pragma unroll
             for (int i = 0; i < 4 * PG; ++i) z[i] = (float)(kg & 1023u) * 1e-3f - 0.5f;
@@ -275,17 +296,21 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
                 constexpr int nloc = 4 * g * PG + i;
                 constexpr int tt = nloc / UD, d = nloc % UD;
                 // libstdc++ normal_distribution: ret * stddev + mean (dd:96-97), then clamp (dd:98-99)
-                double v = (double)z[i] * A.sigma + nomk[nloc];
+                double v = (double)z[i] * A.sigma + nomv[i];
                 v = clampd(v, arg5<d>(A.umin), arg5<d>(A.umax));
                 if constexpr (FB && d == 2) {
                     if (A.steer_off) v = 0.0;   // fb:517
                 }
                 u[tt][d] = v;
+                if constexpr (SH::kStage) {
+                    sh.us[b & 1][nloc][lane] = v;
+                } else {
 #if !defined(CCV_ABL_NO_STORE)
-                // no `live` predicate: rows are padded to a multiple of 64 samples (pitch), lanes past K write their
-                // padding slot -- a branch per store would cut this block into pieces the scheduler cannot interleave
-                A.u[(size_t)(t0 * UD + nloc) * pitch + k] = v;
+                    // no `live` predicate: rows are padded to a multiple of 64 samples (pitch), lanes past K write their
+                    // padding slot -- a branch per store would cut this block into pieces the scheduler cannot interleave
+                    A.u[(size_t)(t0 * UD + nloc) * pitch + k] = v;
 #endif
+                }
             });
         });
     } else {
@@ -393,12 +418,17 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
     for (int tt = 0; tt < kTU; ++tt) {
         xv[tt] = x;
         yv[tt] = y;
-        sh.p[b & 1][tt][0][lane] = x - A.x0[0];
-        sh.p[b & 1][tt][1][lane] = y - A.x0[1];
+        if constexpr (SH::kStage) {
+            sh.p[b & 1][tt][0][lane] = x;
+            sh.p[b & 1][tt][1][lane] = y;
+        } else {
+            sh.p[b & 1][tt][0][lane] = x - A.x0[0];
+            sh.p[b & 1][tt][1][lane] = y - A.x0[1];
+        }
         x = x + u[tt][0] * cs[tt] * dt;
         y = y + u[tt][0] * sn[tt] * dt;
     }
-    if constexpr (MODE != MODE_COST) {
+    if constexpr (MODE != MODE_COST && !SH::kStage) {
 #if !defined(CCV_ABL_NO_STORE)
         if (A.store_xy) {   // one wave-uniform branch for the 16 stores (padded rows: no `live` predicate, as above)
 #pragma unroll
@@ -425,15 +455,19 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, PcShare
 // Straight fp64 FMA/MIN; four window points per iteration so the LDS broadcast reads are covered and the compiler's
 // canonicalising max in front of fmin() is paid once per four minima.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NV, int MODEL>
-__device__ __forceinline__ void pc_consume(const RolloutArgs& A, const PcShared<MODEL>& sh, double& cost, const int b,
-                                           const int lane) {
+template <int NV, int MODEL, class SH>
+__device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, double& cost, const int b, const int lane,
+                                           const int i0 = 0) {   // states i0 .. i0+NV-1 of block b
     const int H4 = (A.H + 3) & ~3;   // the window is padded with c = +inf: four points per iteration, no remainder
     double px[NV], py[NV], m[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        px[i] = sh.p[b & 1][i][0][lane];
-        py[i] = sh.p[b & 1][i][1][lane];
+        px[i] = sh.p[b & 1][i0 + i][0][lane];
+        py[i] = sh.p[b & 1][i0 + i][1][lane];
+        if constexpr (SH::kStage) {   // staged positions are absolute
+            px[i] -= A.x0[0];
+            py[i] -= A.x0[1];
+        }
         m[i] = INFINITY;
     }
     // software pipeline: the coefficients of points j+4..j+7 are read from LDS (broadcast reads) before the ~100 fp64
@@ -492,45 +526,45 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const PcShared<
 constexpr int kUpdRB = 15;                  // rows per LDS batch: 15 * 65 doubles fit one wave's half of sh.p
 constexpr int kUpdCH = 4 * kUpdRB;          // rows whose loads are in flight together (120 VGPRs)
 
-// Control rows are dealt to the wave that produced (stored) them: wave w owns the time blocks s = w, w+2, ... so a wave
-// only re-reads its own stores (program order makes them visible; no vector-memory wait at the block barriers).
-// m = 0 .. count-1 enumerates a wave's rows.
-template <int MODEL>
-struct UpdRows {
-    static constexpr int BR = kTU * udim_of(MODEL);   // control rows per time block
+// Control rows dealt to the waves of a workgroup in units of BR rows: wave w of NW owns units w, w+NW, ...
+// m = 0 .. count()-1 enumerates a wave's rows.  k_rollout_pc: BR = rows of one time block, NW = 2, so that every wave
+// re-reads exactly the rows it stored itself (program order makes them visible; no vector-memory wait at the barriers).
+template <int BR_, int NW_>
+struct UpdRowsT {
+    static constexpr int BR = BR_, NW = NW_;
     int R, wv;
     __device__ __forceinline__ int count() const {
         int n = 0;
-        for (int r0 = wv * BR; r0 < R; r0 += 2 * BR) n += min(BR, R - r0);
+        for (int r0 = wv * BR; r0 < R; r0 += NW * BR) n += min(BR, R - r0);
         return n;
     }
-    __device__ __forceinline__ int row(const int m) const { return ((m / BR) * 2 + wv) * BR + m % BR; }
+    __device__ __forceinline__ int row(const int m) const { return ((m / BR) * NW + wv) * BR + m % BR; }
 };
+template <int MODEL>
+using UpdRows = UpdRowsT<kTU * udim_of(MODEL), kPcWaves>;
 
 // The re-read of this workgroup's controls: the loads of a whole chunk of rows are issued back to back, so the chunk
 // pays one memory latency, not one per batch.  Rows past the end are clamped (loaded, never used).
-template <int MODEL>
-__device__ __forceinline__ void pc_update_fetch(const RolloutArgs& A, double (&v)[kUpdCH], const UpdRows<MODEL>& rows, const int m0,
+template <class ROWS>
+__device__ __forceinline__ void pc_update_fetch(const RolloutArgs& A, double (&v)[kUpdCH], const ROWS& rows, const int m0,
                                                 const int mcount, const int kk) {
     const size_t pitch = (size_t)A.pitch;
 #pragma unroll
     for (int i = 0; i < kUpdCH; ++i) v[i] = A.u[(size_t)rows.row(min(m0 + i, mcount - 1)) * pitch + kk];
 }
 
-template <int MODEL>
-__device__ __forceinline__ void pc_partial_update(const RolloutArgs& A, PcShared<MODEL>& sh, double (&v)[kUpdCH],
-                                                  const UpdRows<MODEL>& rows, const int mcount, const double wgt,
-                                                  const double total, const int lane, const int wv, const int kk,
-                                                  const bool live) {
-    constexpr int UD = udim_of(MODEL);
-    constexpr int RB = kUpdRB;
-    constexpr int STRIDE = kPcSamples + 1; // padded row: lanes (r, q) hit different banks
-    const int R = (A.H - 1) * UD;
-    double* buf = &sh.p[wv][0][0][0];      // 8 * 2 * 64 = 1024 doubles per wave, free after the last consume
+// sum_k w_k * u_k[row] over the 64 samples of the workgroup for this wave's rows -> A.partial[row][workgroup].
+// RB rows at a time through the wave-private LDS buffer `buf` (RB * 65 doubles): every lane drops w*u for each row, then
+// lane (r, q) adds 16 of the 64 entries of row r and two shuffles finish the row.  (The caller has fetched the first
+// chunk into v.)
+template <int RB, class ROWS>
+__device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, double* buf, double (&v)[kUpdCH], const ROWS& rows,
+                                               const int mcount, const double wgt, const int lane, const int kk) {
+    static_assert(RB <= 16 && kUpdCH % RB == 0, "batch size");
+    constexpr int STRIDE = kPcSamples + 1;   // padded row: lanes (r, q) hit different banks
     const int rr = lane >> 2, q = lane & 3;
-    // (the caller has fetched the first chunk into v and passed the barrier that frees sh.p)
     for (int chunk0 = 0; chunk0 < mcount; chunk0 += kUpdCH) {
-        if (chunk0 != 0) pc_update_fetch<MODEL>(A, v, rows, chunk0, mcount, kk);
+        if (chunk0 != 0) pc_update_fetch(A, v, rows, chunk0, mcount, kk);
         static_for<kUpdCH / RB>([&](auto BB) {
             constexpr int bb = decltype(BB)::value;
             const int base = chunk0 + bb * RB;
@@ -552,19 +586,31 @@ __device__ __forceinline__ void pc_partial_update(const RolloutArgs& A, PcShared
             }
         });
     }
-    if (wv == 0) {
-        // sum of weights + cost statistics of this workgroup
-        const double sw = wave_sum(wgt);
-        const double mn = wave_min(live ? total : INFINITY);
-        const double mx = wave_max(live ? total : -INFINITY);
-        const double nz = wave_sum((live && wgt == 0.0) ? 1.0 : 0.0);
-        if (lane == 0) {
-            A.partial[(size_t)R * A.nparts + blockIdx.x] = sw;
-            A.statpart[blockIdx.x * 3 + 0] = mn;
-            A.statpart[blockIdx.x * 3 + 1] = mx;
-            A.statpart[blockIdx.x * 3 + 2] = nz;
-        }
+}
+
+// sum of weights + cost statistics of the workgroup (one wave)
+__device__ __forceinline__ void pc_block_stats(const RolloutArgs& A, const int R, const double wgt, const double total, const bool live,
+                                               const int lane) {
+    const double sw = wave_sum(wgt);
+    const double mn = wave_min(live ? total : INFINITY);
+    const double mx = wave_max(live ? total : -INFINITY);
+    const double nz = wave_sum((live && wgt == 0.0) ? 1.0 : 0.0);
+    if (lane == 0) {
+        A.partial[(size_t)R * A.nparts + blockIdx.x] = sw;
+        A.statpart[blockIdx.x * 3 + 0] = mn;
+        A.statpart[blockIdx.x * 3 + 1] = mx;
+        A.statpart[blockIdx.x * 3 + 2] = nz;
     }
+}
+
+template <int MODEL>
+__device__ __forceinline__ void pc_partial_update(const RolloutArgs& A, PcShared<MODEL>& sh, double (&v)[kUpdCH],
+                                                  const UpdRows<MODEL>& rows, const int mcount, const double wgt,
+                                                  const double total, const int lane, const int wv, const int kk,
+                                                  const bool live) {
+    // sh.p: 8 * 2 * 64 = 1024 doubles per wave, free after the last consume (the caller has passed the barrier)
+    pc_reduce_rows<kUpdRB>(A, &sh.p[wv][0][0][0], v, rows, mcount, wgt, lane, kk);
+    if (wv == 0) pc_block_stats(A, (A.H - 1) * udim_of(MODEL), wgt, total, live, lane);
 }
 
 template <int MODEL, int MODE>
@@ -582,6 +628,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
             sh.c[j] = j < H ? W.c[j] : INFINITY;
         }
     }
+    if constexpr (MODE == MODE_FUSED) pc_stage_nominal<MODEL>(A, sh, kPcWaves * 64);
     const int k = blockIdx.x * kPcSamples + lane;
     const bool live = k < A.K;
     const int kk = live ? k : A.K - 1;
@@ -705,7 +752,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
         const UpdRows<MODEL> rows{(H - 1) * udim_of(MODEL), wv};
         const int mcount = A.fuse_update ? rows.count() : 0;
         // start the re-read of this wave's controls before anything else (see pc_update_fetch)
-        if (mcount > 0) pc_update_fetch<MODEL>(A, upd, rows, 0, mcount, kk);
+        if (mcount > 0) pc_update_fetch(A, upd, rows, 0, mcount, kk);
         sh.cost[wv][lane] = cost;
         pc_barrier_lds();   // also: everyone is done with sh.p
         const double total = sh.cost[0][lane] + sh.cost[1][lane];

@@ -1,0 +1,190 @@
+// Three-wave rollout kernel for gfx950 (MI355X): one workgroup = 64 samples = producer wave + distance wave + store wave.
+//
+// Issuing a 512-byte global store costs the issuing wave 45-120 cycles on this chip (tools/microbench/store_issue.hip:
+// the CU's store path moves ~10 B/cycle for one wave, ~30 B/cycle with eight), and the rollout stores 198 rows per
+// workgroup: in k_rollout_pc (mppi_rollout_pc.h) that is ~11 % of the producer's time, on the critical chain of the
+// workgroup.  Here a third wave does nothing but stores:
+//
+//   wave 0 (producer)   sampling + dynamics + control costs of time block s; the rollout state stays in its registers
+//                       from block to block; clamped controls and (x, y) go to LDS, double buffered
+//   wave 1 (distance)   min over the window points of the squared distance for the states of block s-1 (the O(K T^2) part)
+//   wave 2 (store)      controls and states of block s-1: LDS -> HBM; it is the wave that waits on the store path
+//
+// One LDS barrier per time block.  With three waves per workgroup the chip also holds three waves per SIMD at K = 65 536.
+// The epilogue (weights, fused sum w*u partials) deals the control rows to all three waves.  Arithmetic, noise and the
+// summation order inside a row are those of k_rollout_pc; only the per-sample cost is the sum of the producer's and the
+// distance wave's parts.
+#pragma once
+#include "mppi_rollout_pc.h"
+
+namespace ccv {
+
+constexpr int kR3Waves = 3;
+// states of a block whose distance the distance wave computes; the store wave would take the rest.  8: measured best
+// (6 + 2 is 4 us slower at K = 65 536: with eight waves per CU storing, the store wave is busy most of a block time)
+constexpr int kR3CStates = 8;
+constexpr int kR3RB = 12;   // rows per LDS transpose batch in the epilogue: 3 waves x 12 x 65 doubles fit p + ab + c
+
+template <int MODEL>
+struct R3Shared {
+    static constexpr bool kStage = true;
+    // (p, ab, c are contiguous and are reused as the epilogue's transpose buffers)
+    double p[2][kTU][2][kPcSamples];                       // absolute (x,y) of the 8 states of a block, double buffered
+    double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
+    double c[kMaxH + 4];
+    double cost[kR3Waves][kPcSamples];
+    alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u*
+    double us[2][kTU * udim_of(MODEL)][kPcSamples];        // clamped controls of a block, double buffered
+};
+
+template <int MODEL, int MODE>
+__global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutArgs A, const Window W) {
+    constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
+    constexpr bool COST = MODE != MODE_ROLLOUT;
+    __shared__ R3Shared<MODEL> sh;
+    static_assert(sizeof(sh.p) + sizeof(sh.ab) + sizeof(sh.c) >= kR3Waves * kR3RB * (kPcSamples + 1) * sizeof(double), "epilogue buffers");
+    const int H = A.H;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (COST) {
+        const int H4 = (H + 3) & ~3;
+        for (int j = threadIdx.x; j < H4; j += kR3Waves * 64) {
+            sh.ab[j] = j < H ? make_double2(W.a[j], W.b[j]) : make_double2(0.0, 0.0);
+            sh.c[j] = j < H ? W.c[j] : INFINITY;
+        }
+    }
+    if constexpr (MODE == MODE_FUSED) pc_stage_nominal<MODEL>(A, sh, kR3Waves * 64);
+    const int k = blockIdx.x * kPcSamples + lane;
+    const bool live = k < A.K;
+    const int kk = live ? k : A.K - 1;
+    const uint32_t kg = (uint32_t)(A.k_offset + kk);
+    double cost = 0.0;
+    const int nblocks = (H + kTU - 1) / kTU;
+    const int nstates = FB ? H - 2 : H;   // states that reach the path cost (dd:199 / fb:409)
+    __syncthreads();
+    if (wv == 0) {
+        // ---------------- producer: all time blocks, state in registers
+#if defined(CCV_R3_PRIO)
+        __builtin_amdgcn_s_setprio(CCV_R3_PRIO);   // the producer chain is the critical path of the workgroup
+#endif
+        if constexpr (FB && COST) cost += A.w_yaw * (A.x0[2] - A.yaw_ref0) * (A.x0[2] - A.yaw_ref0);   // fb:408
+        PcState<MODEL> S;
+        S.x = A.x0[0];
+        S.y = A.x0[1];
+        S.yaw = A.x0[2];
+        S.roll = A.x0[3];
+        S.pitch = A.x0[4];
+        S.p_v = S.p_rv = S.p_sdir = S.p_c2 = S.p_c3 = S.p_ac = 0.0;
+        S.p_cdir = 1.0;
+#if defined(CCV_STAMP)
+        PcStamps ST;   // (diagnostic builds: the producer's stamp slots are not read back for this kernel)
+        for (int i = 0; i < 8; ++i) ST.acc[i] = 0;
+        ST.last = 0;
+#endif
+        for (int s = 0; s <= nblocks; ++s) {
+            if (s < nblocks) {
+                bool done = false;
+                if (s * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, s, lane, k, kk, live, kg
+#if defined(CCV_STAMP)
+                                                                                  , ST
+#endif
+                );
+                if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, s, lane, k, kk, live, kg);
+            }
+            pc_barrier_lds();
+        }
+    } else if (wv == 1) {
+        // ---------------- distance wave: the first kR3CStates states of block s-1
+        for (int s = 0; s <= nblocks; ++s) {
+            if constexpr (COST) {
+                if (s >= 1) {
+                    const int b = s - 1;
+                    const int nv = min(kR3CStates, nstates - b * kTU);
+                    switch (nv) {
+                        case 8: pc_consume<8, MODEL>(A, sh, cost, b, lane); break;
+                        case 7: pc_consume<7, MODEL>(A, sh, cost, b, lane); break;
+                        case 6: pc_consume<6, MODEL>(A, sh, cost, b, lane); break;
+                        case 5: pc_consume<5, MODEL>(A, sh, cost, b, lane); break;
+                        case 4: pc_consume<4, MODEL>(A, sh, cost, b, lane); break;
+                        case 3: pc_consume<3, MODEL>(A, sh, cost, b, lane); break;
+                        case 2: pc_consume<2, MODEL>(A, sh, cost, b, lane); break;
+                        case 1: pc_consume<1, MODEL>(A, sh, cost, b, lane); break;
+                        default: break;
+                    }
+                }
+            }
+            pc_barrier_lds();
+        }
+    } else {
+        // ---------------- store wave: controls (sampled here: MODE_FUSED) and states (not in MODE_COST) of block s-1
+        constexpr int UD = udim_of(MODEL);
+        const size_t pitch = (size_t)A.pitch;
+        for (int s = 0; s <= nblocks; ++s) {
+            if (s >= 1) {
+                const int b = s - 1, t0 = b * kTU;
+#if !defined(CCV_ABL_NO_STORE)
+                if constexpr (MODE == MODE_FUSED) {
+                    const int nrows = min(kTU, H - 1 - t0) * UD;   // control steps t < H-1
+#pragma unroll
+                    for (int r = 0; r < kTU * UD; ++r) {
+                        // rows are padded to a multiple of 64 samples (pitch): lanes past K write their padding slot
+                        if (r < nrows) A.u[(size_t)(t0 * UD + r) * pitch + k] = sh.us[b & 1][r][lane];
+                    }
+                }
+                if constexpr (MODE != MODE_COST) {
+                    if (A.store_xy) {
+                        const int nst = min(kTU, H - t0);           // states t < H
+#pragma unroll
+                        for (int tt = 0; tt < kTU; ++tt) {
+                            if (tt < nst) {
+                                CCV_STATE_STORE(&A.xs[(size_t)(t0 + tt) * pitch + k], sh.p[b & 1][tt][0][lane]);
+                                CCV_STATE_STORE(&A.ys[(size_t)(t0 + tt) * pitch + k], sh.p[b & 1][tt][1][lane]);
+                            }
+                        }
+                    }
+                }
+#endif
+            }
+            if constexpr (COST && kR3CStates < kTU) {
+                if (s >= 1) {   // (experiment: the store wave also takes the last states)
+                    const int b = s - 1;
+                    const int nv = min(kTU - kR3CStates, nstates - b * kTU - kR3CStates);
+                    if (nv == 2) pc_consume<2, MODEL>(A, sh, cost, b, lane, kR3CStates);
+                    else if (nv == 1) pc_consume<1, MODEL>(A, sh, cost, b, lane, kR3CStates);
+                }
+            }
+            // the other two waves re-read the control rows in the epilogue: all of this wave's stores are acknowledged
+            // before the last barrier
+            if (s == nblocks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pc_barrier_lds();
+        }
+    }
+#if defined(CCV_R3_PRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    if constexpr (COST) {
+        using Rows = UpdRowsT<kR3RB, kR3Waves>;
+        const int R = (H - 1) * udim_of(MODEL);
+        double upd[kUpdCH];
+        const Rows rows{R, wv};
+        const int mcount = A.fuse_update ? rows.count() : 0;
+        // start the re-read of this wave's share of the controls before anything else (see pc_update_fetch)
+        if (mcount > 0) pc_update_fetch(A, upd, rows, 0, mcount, kk);
+        sh.cost[wv][lane] = cost;
+        pc_barrier_lds();
+        const double total = (sh.cost[0][lane] + sh.cost[1][lane]) + sh.cost[2][lane];
+        const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
+        if (wv == 0 && live) {
+            A.cost[k] = total;
+            A.w[k] = wgt;
+        }
+        if (A.fuse_update) {
+            // p, ab, c are dead (the loop's last barrier): a private transpose buffer per wave
+            double* buf = &sh.p[0][0][0][0] + wv * (kR3RB * (kPcSamples + 1));
+            pc_reduce_rows<kR3RB>(A, buf, upd, rows, mcount, wgt, lane, kk);
+            if (wv == kR3Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
+        }
+    }
+}
+
+}  // namespace ccv

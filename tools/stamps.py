@@ -91,3 +91,11 @@ print("epilogue (kernel end - loop end, wave 0) histogram:", np.histogram(ep, bi
 order = np.argsort(fin_us)
 print("last 6 blocks to end: ", [(int(i), round(float(end0_us[i]), 1), round(float(fin_us[i]), 1)) for i in order[-6:]])
 
+# placement of the workgroups of a few CUs: (block id, SIMD / wave slot of wave 0, SIMD / wave slot of wave 1, loop duration)
+print("placement (first 6 CUs): block: w0 simd/slot, w1 simd/slot, loop us")
+seen = {}
+for i in range(nb):
+    seen.setdefault(int(cuid[i]), []).append(i)
+for cu_k in sorted(seen)[:6]:
+    print("  cu %d: " % cu_k + "; ".join("%d: %d/%d %d/%d %.1f" % (i, h0["simd"][i], h0["wave"][i], h1["simd"][i], h1["wave"][i], dur[i])
+                                        for i in seen[cu_k]))
