@@ -61,6 +61,7 @@ struct ccv_mppi_handle {
     // CCV_MPPI_WINDOW=scalar -> its scalar-load window variant; default = k_rollout_pc
     int lds_window = 1;
     int coop = 1;
+    int prio_rotate = 0, cu_count = 256;   // pc_rotate_priority (mppi_rollout_pc.h)
     double inj_absmax[CCV_MPPI_MAX_UDIM] = {0, 0, 0, 0, 0};   // largest |control| per dimension in the buffer (sampled: clamp bound)
     // timing
     bool timing = false;
@@ -156,6 +157,8 @@ void fill_args(const ccv_mppi_handle* h, RolloutArgs& A, const double* x0, doubl
     A.statpart = h->d_statpart;
     A.nparts = h->nblocks;
     A.fuse_update = 0;
+    A.prio_rotate = h->prio_rotate;
+    A.cu_count = h->cu_count;
     A.dbg = h->d_dbg;
 }
 
@@ -442,6 +445,8 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     if (h->coop && h->cfg.model == CCV_MPPI_DIFF_DRIVE) h->coop = 2;
     if (h->coop && kenv && std::strcmp(kenv, "r3") == 0) h->coop = 2;
     if (h->coop && kenv && std::strcmp(kenv, "pc") == 0) h->coop = 1;
+    h->prio_rotate = h->coop == 2 ? 1 : 0;   // measured: -4 us on the three-wave kernel, no gain on the two-wave one
+    if (const char* pv = std::getenv("CCV_MPPI_PRIO")) h->prio_rotate = std::strcmp(pv, "0") != 0;
 
     auto bail = [&](int code, const char* what, hipError_t e) {
         fail(h, code, what, e);
@@ -451,6 +456,10 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     };
     hipError_t e;
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail(CCV_MPPI_ERR_NO_DEVICE, "hipSetDevice", e);
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) h->cu_count = ncu;
+    }
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipStreamCreate", e);
     h->stream = h->own_stream;
     const size_t P = (size_t)h->pitch;

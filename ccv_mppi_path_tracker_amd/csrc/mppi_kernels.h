@@ -63,6 +63,7 @@ struct RolloutArgs {
     double* partial;    // fused update: [(R+1)][nparts] per-workgroup sums of w and w*u (null: not fused)
     double* statpart;   // [nparts][3]: min cost, max cost, zero-weight count
     int32_t nparts, fuse_update;
+    int32_t prio_rotate, cu_count;   // k_rollout_pc / k_rollout_r3: see pc_rotate_priority()
     unsigned long long* dbg;   // diagnostic builds only (CCV_STAMP): per-phase cycle sums
 };
 

@@ -90,6 +90,18 @@ __device__ __forceinline__ void pc_stage_nominal(const RolloutArgs& A, SH& sh, c
 #define CCV_STATE_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #endif
 
+// Wave arbitration on a SIMD is by priority, then age: with every workgroup at priority 0 the workgroup dispatched first
+// to a CU runs almost unimpeded and the last one gets the left-over issue slots -- measured at K = 65 536, four
+// workgroups per CU: 26 / 33 / 41 / 45 us for the same work, and the kernel ends with the slowest.  Alternating which
+// half of a CU's workgroups is favoured, once per time block, evens them out (28 / 33 / 39 / 40 us; kernel -4 us).
+// rank = position of the workgroup in its CU's dispatch order (workgroups go round-robin over the CUs).
+__device__ __forceinline__ void pc_rotate_priority(const RolloutArgs& A, const int s) {
+    if (!A.prio_rotate) return;
+    const int rank = (int)blockIdx.x / A.cu_count;
+    if ((rank ^ s) & 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 // Workgroup barrier for the block hand-off.  The two waves exchange data through LDS only, so the barrier waits for LDS
 // (lgkmcnt) and not, as __syncthreads() does, for the acknowledgement of every control / state store still in flight.
 __device__ __forceinline__ void pc_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -648,6 +660,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
 #endif
     for (int s = 0; s <= nblocks; ++s) {
         CCV_STAMP_AT(ST, 7);
+        pc_rotate_priority(A, s);
         if (s < nblocks && (s & 1) == wv) {
             // ---------------- produce block s
 #if defined(CCV_EXP_PRIO)
@@ -733,6 +746,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
         pc_barrier_lds();
         CCV_STAMP_AT(ST, 6);
     }
+    if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
 #if defined(CCV_STAMP)
     if (A.dbg && lane == 0 && blockIdx.x == 3) {
         for (int i = 0; i < 8; ++i) A.dbg[wv * 8 + i] = ST.acc[i];

@@ -62,11 +62,11 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
     const int nblocks = (H + kTU - 1) / kTU;
     const int nstates = FB ? H - 2 : H;   // states that reach the path cost (dd:199 / fb:409)
     __syncthreads();
+#if defined(CCV_STAMP)
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (wv == 0) {
         // ---------------- producer: all time blocks, state in registers
-#if defined(CCV_R3_PRIO)
-        __builtin_amdgcn_s_setprio(CCV_R3_PRIO);   // the producer chain is the critical path of the workgroup
-#endif
         if constexpr (FB && COST) cost += A.w_yaw * (A.x0[2] - A.yaw_ref0) * (A.x0[2] - A.yaw_ref0);   // fb:408
         PcState<MODEL> S;
         S.x = A.x0[0];
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
         ST.last = 0;
 #endif
         for (int s = 0; s <= nblocks; ++s) {
+            pc_rotate_priority(A, s);
             if (s < nblocks) {
                 bool done = false;
                 if (s * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, s, lane, k, kk, live, kg
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
     } else if (wv == 1) {
         // ---------------- distance wave: the first kR3CStates states of block s-1
         for (int s = 0; s <= nblocks; ++s) {
+            pc_rotate_priority(A, s);
             if constexpr (COST) {
                 if (s >= 1) {
                     const int b = s - 1;
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
         constexpr int UD = udim_of(MODEL);
         const size_t pitch = (size_t)A.pitch;
         for (int s = 0; s <= nblocks; ++s) {
+            pc_rotate_priority(A, s);
             if (s >= 1) {
                 const int b = s - 1, t0 = b * kTU;
 #if !defined(CCV_ABL_NO_STORE)
@@ -159,8 +162,17 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
             pc_barrier_lds();
         }
     }
-#if defined(CCV_R3_PRIO)
-    __builtin_amdgcn_s_setprio(0);
+    if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
+#if defined(CCV_STAMP)
+    if (A.dbg && lane == 0 && blockIdx.x < 4096 && wv < 2) {
+        // per block: [start, loop end wave 0, hw id wave 0, loop end wave 1, hw id wave 1, kernel end wave 0]
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        unsigned int hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        unsigned int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+        if (wv == 0) A.dbg[64 + blockIdx.x * 6 + 0] = rt0;
+        A.dbg[64 + blockIdx.x * 6 + 1 + 2 * wv] = rt1;
+        A.dbg[64 + blockIdx.x * 6 + 2 + 2 * wv] = ((unsigned long long)xcc << 32) | hwid;
+    }
 #endif
     if constexpr (COST) {
         using Rows = UpdRowsT<kR3RB, kR3Waves>;
@@ -185,6 +197,12 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
             if (wv == kR3Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
         }
     }
+#if defined(CCV_STAMP)
+    if (A.dbg && lane == 0 && wv == 0 && blockIdx.x < 4096) {
+        __builtin_amdgcn_s_waitcnt(0);
+        A.dbg[64 + blockIdx.x * 6 + 5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 }  // namespace ccv
