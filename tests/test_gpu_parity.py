@@ -201,6 +201,31 @@ def test_kernel_variants_agree(monkeypatch, name):
     np.testing.assert_array_equal(res[1], res[2])
 
 
+@pytest.mark.parametrize("K,H", [(256, 50), (1000, 50), (130, 9), (64, 3), (4097, 128)])
+def test_two_wave_and_three_wave_kernels_agree(monkeypatch, K, H):
+    """Diff-drive runs the three-wave kernel (producer / distance / store wave, mppi_rollout_r3.h) by default; the
+    two-wave kernel (mppi_rollout_pc.h, the one steering / full body use) must give the same samples, states and
+    per-sample costs bit for bit -- same arithmetic, only a different split over waves -- and the same controls up to the
+    order in which the per-wave cost parts are added.  The wave-priority rotation must not change anything."""
+    p = configs.workload("C2").params.with_(num_samples=K, horizon=H)
+    path = helpers.oracle_path("sinusoid")
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    monkeypatch.setenv("CCV_MPPI_KERNEL", "r3")
+    a = MPPIController(p)
+    monkeypatch.setenv("CCV_MPPI_PRIO", "0")
+    a0 = MPPIController(p)
+    monkeypatch.setenv("CCV_MPPI_KERNEL", "pc")
+    b = MPPIController(p)
+    res = [g.iterate(state, p.dt, xr, yr, yaw[0], 11, 4, want_stats=False) for g in (a, a0, b)]
+    np.testing.assert_array_equal(res[0], res[1])
+    np.testing.assert_array_equal(a.read_costs(), a0.read_costs())
+    np.testing.assert_array_equal(a.read_controls(), b.read_controls())
+    np.testing.assert_array_equal(a.read_candidates(), b.read_candidates())
+    np.testing.assert_allclose(a.read_costs(), b.read_costs(), rtol=1e-14)
+    np.testing.assert_allclose(res[0], res[2], rtol=1e-11, atol=1e-15)
+
+
 # --------------------------------------------------------------------------------------------------------------
 # edge cases
 # --------------------------------------------------------------------------------------------------------------
