@@ -29,6 +29,7 @@ struct ccv_mppi_handle {
     hipStream_t stream = nullptr;
     // device buffers
     double* d_nominal = nullptr;
+    const double* pending_vec = nullptr;   // deferred apply_partials: u* = pending_vec[1..] / pending_vec[0] (see flush_pending)
     double* d_u = nullptr;
     double* d_xs = nullptr;
     double* d_ys = nullptr;
@@ -158,6 +159,9 @@ void fill_args(const ccv_mppi_handle* h, RolloutArgs& A, const double* x0, doubl
     A.nparts = h->nblocks;
     A.fuse_update = 0;
     A.prio_rotate = h->prio_rotate;
+    A.pending_vec = nullptr;
+    A.nominal_w = h->d_nominal;
+    A.stats_w = h->d_stats;
     A.cu_count = h->cu_count;
     A.dbg = h->d_dbg;
 }
@@ -214,6 +218,16 @@ void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const 
     }
 }
 
+// A deferred ccv_mppi_apply_partials_enqueue is normally consumed by the next fused rollout launch (pc_stage_nominal);
+// anything else that reads the warm start first gets it materialised here.
+int flush_pending(ccv_mppi_handle* h) {
+    if (!h->pending_vec) return CCV_MPPI_OK;
+    hipLaunchKernelGGL(k_apply_partials, dim3(1), dim3(kBlock), 0, h->stream, h->pending_vec, h->d_nominal, h->d_stats, h->R);
+    h->pending_vec = nullptr;
+    HIP_TRY(h, hipGetLastError());
+    return CCV_MPPI_OK;
+}
+
 // k_rollout_pc uses a branch-free sin/cos that is valid for |angle| <= kFastTrigLimit.  Every heading a sample can
 // reach is bounded by the start angle plus (H-1) steps at the largest control magnitude, so the decision is made here,
 // once per call; anything else (huge or non-finite angles, unbounded injected controls) runs the plain
@@ -242,6 +256,15 @@ int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A_in, const Window& W,
     // the production kernel also reduces its workgroup's share of sum w and sum w*u (no second pass over the controls);
     // the underflow-safe MIN_SHIFT mode needs the global minimum first and keeps the separate update kernels
     A.fuse_update = (h->coop && mode != MODE_ROLLOUT && !(h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT)) ? 1 : 0;
+    if (h->pending_vec) {
+        if (h->coop && mode == MODE_FUSED) {   // the kernel divides while it stages u* (and writes it back)
+            A.pending_vec = h->pending_vec;
+            h->pending_vec = nullptr;
+        } else {
+            int rc = flush_pending(h);
+            if (rc) return rc;
+        }
+    }
     if (mode != MODE_ROLLOUT) h->nparts_last = A.fuse_update ? h->nblocks : 0;
     switch (h->cfg.model) {
         case CCV_MPPI_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_DIFF_DRIVE>(h, A, W, mode); break;
@@ -253,6 +276,7 @@ int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A_in, const Window& W,
 }
 
 int launch_sample(ccv_mppi_handle* h, const RolloutArgs& A) {
+    if (int rc = flush_pending(h)) return rc;
     const dim3 grid((h->K + kBlock - 1) / kBlock, (h->R + 3) / 4), block(kBlock);
     switch (h->cfg.model) {
         case CCV_MPPI_DIFF_DRIVE: hipLaunchKernelGGL((k_sample<CCV_MPPI_DIFF_DRIVE>), grid, block, 0, h->stream, A); break;
@@ -376,6 +400,7 @@ int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const dou
 }
 
 int fetch_result(ccv_mppi_handle* h, double* u_opt_out, ccv_mppi_stats* stats) {
+    if (int rc = flush_pending(h)) return rc;
     // one D2H of [u* | stats] through pinned memory, then a stream sync
     const size_t n = (size_t)h->R;
     HIP_TRY(h, hipMemcpyAsync(h->h_pin, h->d_nominal, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -512,6 +537,7 @@ int ccv_mppi_destroy(ccv_mppi_handle* h) {
 
 int ccv_mppi_set_stream(ccv_mppi_handle* h, void* hip_stream) {
     if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (int rc = flush_pending(h)) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     for (bool& u : h->throttle_used) u = false;   // marks recorded on the old stream are complete (synchronised above)
@@ -544,12 +570,14 @@ extern "C" int ccv_mppi_debug_blocks(ccv_mppi_handle* h, unsigned long long* out
 
 int ccv_mppi_synchronize(ccv_mppi_handle* h) {
     if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (int rc = flush_pending(h)) return rc;   // (after this the caller may free the partials buffer)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CCV_MPPI_OK;
 }
 
 int ccv_mppi_set_nominal(ccv_mppi_handle* h, const double* u) {
     if (!h || !u) return CCV_MPPI_ERR_INVALID_ARG;
+    h->pending_vec = nullptr;   // overwritten anyway
     HIP_TRY(h, hipMemcpyAsync(h->d_nominal, u, (size_t)h->R * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CCV_MPPI_OK;
@@ -557,6 +585,7 @@ int ccv_mppi_set_nominal(ccv_mppi_handle* h, const double* u) {
 
 int ccv_mppi_get_nominal(ccv_mppi_handle* h, double* u) {
     if (!h || !u) return CCV_MPPI_ERR_INVALID_ARG;
+    if (int rc = flush_pending(h)) return rc;
     HIP_TRY(h, hipMemcpyAsync(u, h->d_nominal, (size_t)h->R * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CCV_MPPI_OK;
@@ -593,8 +622,11 @@ int ccv_mppi_iterate_partials_enqueue(ccv_mppi_handle* h, const double* x0, doub
 
 int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partials) {
     if (!h || !dev_partials) return CCV_MPPI_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_apply_partials, dim3(1), dim3(kBlock), 0, h->stream, dev_partials, h->d_nominal, h->d_stats, h->R);
-    HIP_TRY(h, hipGetLastError());
+    // deferred: the next fused rollout launch on this handle forms u* = V / S while it stages the warm start (one kernel
+    // launch less per iteration); any other reader of the warm start triggers k_apply_partials first (flush_pending)
+    int rc = flush_pending(h);
+    if (rc) return rc;
+    h->pending_vec = dev_partials;
     return CCV_MPPI_OK;
 }
 

@@ -64,6 +64,11 @@ struct RolloutArgs {
     double* statpart;   // [nparts][3]: min cost, max cost, zero-weight count
     int32_t nparts, fuse_update;
     int32_t prio_rotate, cu_count;   // k_rollout_pc / k_rollout_r3: see pc_rotate_priority()
+    // deferred ccv_mppi_apply_partials_enqueue (K sharded over devices): when set, the warm start is pending_vec[1..] /
+    // pending_vec[0]; every workgroup forms it while staging u* in LDS and workgroup 0 writes it (and sum w) back
+    const double* pending_vec;
+    double* nominal_w;
+    double* stats_w;
     unsigned long long* dbg;   // diagnostic builds only (CCV_STAMP): per-phase cycle sums
 };
 

@@ -78,6 +78,18 @@ struct PcShared {
 template <int MODEL, class SH>
 __device__ __forceinline__ void pc_stage_nominal(const RolloutArgs& A, SH& sh, const int nthreads) {
     const int R = (A.H - 1) * udim_of(MODEL);
+    if (A.pending_vec) {
+        // K sharded over devices: the all-reduced [sum w, sum w*u] has not been divided yet -- do it here (the division
+        // k_apply_partials would do, bit for bit) instead of spending a kernel launch on 100 quotients
+        const double S = A.pending_vec[0];
+        for (int j = threadIdx.x; j < R + 8; j += nthreads) {
+            const double v = j < R ? A.pending_vec[1 + j] / S : 0.0;
+            sh.nom[j] = v;
+            if (blockIdx.x == 0 && j < R) A.nominal_w[j] = v;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) A.stats_w[0] = S;
+        return;
+    }
     for (int j = threadIdx.x; j < R + 8; j += nthreads) sh.nom[j] = j < R ? A.nominal[j] : 0.0;
 }
 

@@ -145,7 +145,9 @@ int ccv_mppi_partials_size(const ccv_mppi_handle* h);
 int ccv_mppi_iterate_partials_enqueue(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref,
                                       const double* y_ref, double yaw_ref0, uint64_t seed, uint64_t iter,
                                       double* dev_partials);
-/* u* = partials[1:] / partials[0], written to the resident warm start (no host sync). */
+/* u* = partials[1:] / partials[0] becomes the resident warm start (no host sync).  The division is deferred into the
+ * next ccv_mppi_iterate*_enqueue on this handle (one kernel launch less per iteration); dev_partials must stay valid and
+ * unchanged until then, or until ccv_mppi_synchronize / ccv_mppi_get_nominal, which perform it at once. */
 int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partials);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */

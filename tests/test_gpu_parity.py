@@ -476,6 +476,45 @@ def test_shard_invariance_via_partials(wl, K):
     np.testing.assert_array_equal(a.get_nominal(), b.get_nominal())
 
 
+@pytest.mark.parametrize("wl,K", [("C2", 4096), ("C3", 2048), ("C4", 1024)])
+def test_sharded_loop_with_deferred_apply(wl, K):
+    """Several iterations of the K-sharded loop on two handles (sum of the partial vectors standing in for the
+    all-reduce).  ccv_mppi_apply_partials_enqueue is deferred: the next rollout launch divides V by S while it stages the
+    warm start.  The loop must follow the single-handle loop, and the warm start read back afterwards must be the one the
+    kernel wrote."""
+    import torch
+    w = configs.workload(wl, num_samples=K)
+    p = w.params
+    path = helpers.oracle_path(w.path)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    whole = MPPIController(p)
+    cut = K // 2 + 64
+    a, b = MPPIController(p, num_samples=cut), MPPIController(p, num_samples=K - cut, sample_offset=cut)
+    n = a.partials_size()
+    pa = torch.zeros(n, dtype=torch.float64, device="cuda")
+    pb = torch.zeros(n, dtype=torch.float64, device="cuda")
+    tot = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for it in range(4):
+        u_whole = whole.iterate(state, p.dt, xr, yr, yaw[0], 5, it, want_stats=False)
+        a.iterate_partials_enqueue(state, p.dt, xr, yr, yaw[0], 5, it, pa.data_ptr())
+        b.iterate_partials_enqueue(state, p.dt, xr, yr, yaw[0], 5, it, pb.data_ptr())
+        a.synchronize()
+        b.synchronize()
+        tot.copy_(pa + pb)
+        torch.cuda.synchronize()
+        a.apply_partials_enqueue(tot.data_ptr())   # deferred into the next iterate_partials_enqueue
+        b.apply_partials_enqueue(tot.data_ptr())
+    # the last apply is still pending here: get_nominal performs it
+    np.testing.assert_allclose(a.get_nominal(), u_whole, rtol=1e-9, atol=1e-13)
+    np.testing.assert_array_equal(a.get_nominal(), b.get_nominal())
+    # and a warm start written by the kernel itself (deferred apply consumed by a launch) is what get_nominal returns
+    a.apply_partials_enqueue(tot.data_ptr())
+    a.iterate_partials_enqueue(state, p.dt, xr, yr, yaw[0], 5, 9, pa.data_ptr())
+    a.synchronize()
+    np.testing.assert_array_equal(a.get_nominal().ravel(), (tot[1:] / tot[0]).cpu().numpy())
+
+
 def test_closed_loop_matches_oracle_and_tracks():
     """Closed loop in the spirit of record_state.py / calc_e_rmse.py:30-49: the GPU controller and the oracle
     (philox mode) drive the same kinematic plant along the launch sinusoid and must stay together."""
