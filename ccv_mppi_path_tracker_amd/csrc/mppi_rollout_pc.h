@@ -603,8 +603,8 @@ __device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, double* buf
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc += buf[rr * STRIDE + q * 16 + i];
                 }
-                acc += __shfl_xor(acc, 1, 64);
-                acc += __shfl_xor(acc, 2, 64);
+                acc += dpp_move<kDppXor1>(acc);   // the four lanes of a row are one quad
+                acc += dpp_move<kDppXor2>(acc);
                 if (rr < nrows && q == 0) A.partial[(size_t)rows.row(base + rr) * A.nparts + blockIdx.x] = acc;
                 __builtin_amdgcn_wave_barrier();
             }
