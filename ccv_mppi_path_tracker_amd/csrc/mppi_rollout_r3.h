@@ -64,6 +64,18 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
     __syncthreads();
 #if defined(CCV_STAMP)
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r3_work = 0, r3_t0, r3_t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r3_t0)::"memory");
+    const unsigned long long r3_begin = r3_t0;
+#define R3_BARRIER()                                                                          \
+    do {                                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r3_t1)::"memory");         \
+        r3_work += r3_t1 - r3_t0;                                                              \
+        pc_barrier_lds();                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r3_t0)::"memory");         \
+    } while (0)
+#else
+#define R3_BARRIER() pc_barrier_lds()
 #endif
     if (wv == 0) {
         // ---------------- producer: all time blocks, state in registers
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
                 );
                 if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, s, lane, k, kk, live, kg);
             }
-            pc_barrier_lds();
+            R3_BARRIER();
         }
     } else if (wv == 1) {
         // ---------------- distance wave: the first kR3CStates states of block s-1
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
                     }
                 }
             }
-            pc_barrier_lds();
+            R3_BARRIER();
         }
     } else {
         // ---------------- store wave: controls (sampled here: MODE_FUSED) and states (not in MODE_COST) of block s-1
@@ -159,11 +171,17 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
             // the other two waves re-read the control rows in the epilogue: all of this wave's stores are acknowledged
             // before the last barrier
             if (s == nblocks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            pc_barrier_lds();
+            R3_BARRIER();
         }
     }
     if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
 #if defined(CCV_STAMP)
+    if (A.dbg && lane == 0 && (blockIdx.x == 3 || blockIdx.x == 771)) {
+        // [work cycles, loop cycles] per wave: block 3 (first on its CU) -> slots 0..5, block 771 (last) -> slots 8..13
+        const int o = blockIdx.x == 3 ? 0 : 8;
+        A.dbg[o + wv * 2 + 0] = r3_work;
+        A.dbg[o + wv * 2 + 1] = r3_t0 - r3_begin;
+    }
     if (A.dbg && lane == 0 && blockIdx.x < 4096 && wv < 2) {
         // per block: [start, loop end wave 0, hw id wave 0, loop end wave 1, hw id wave 1, kernel end wave 0]
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();

@@ -99,3 +99,8 @@ for i in range(nb):
 for cu_k in sorted(seen)[:6]:
     print("  cu %d: " % cu_k + "; ".join("%d: %d/%d %d/%d %.1f" % (i, h0["simd"][i], h0["wave"][i], h1["simd"][i], h1["wave"][i], dur[i])
                                         for i in seen[cu_k]))
+if os.environ.get("CCV_MPPI_KERNEL", "") != "pc" and wl == "C2":
+    raw = np.array(list(out), dtype=np.float64)
+    for name, o in (("block 3 (first on its CU)", 0), ("block 771 (last on its CU)", 8)):
+        print("three-wave kernel, %s: work / loop cycles  producer %.0f/%.0f  distance %.0f/%.0f  store %.0f/%.0f"
+              % ((name,) + tuple(raw[o:o + 6])))
