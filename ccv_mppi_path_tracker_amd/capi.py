@@ -68,6 +68,7 @@ SIGNATURES = {
     "ccv_mppi_weights": (C.c_int, [_H, _dp, _dp, C.c_double]),
     "ccv_mppi_update": (C.c_int, [_H, _dp, C.POINTER(Stats)]),
     "ccv_mppi_read_candidates": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, _dp]),
+    "ccv_mppi_read_top_candidates": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int32), _dp, _dp]),
     "ccv_mppi_read_costs": (C.c_int, [_H, C.c_int32, C.c_int32, _dp]),
     "ccv_mppi_read_weights": (C.c_int, [_H, C.c_int32, C.c_int32, _dp]),
     "ccv_mppi_read_controls": (C.c_int, [_H, C.c_int32, C.c_int32, _dp]),

@@ -136,6 +136,15 @@ class MPPIController:
         self._check(self.lib.ccv_mppi_read_candidates(self._h, first, count, stride, capi.dptr(out)))
         return out
 
+    def read_top_candidates(self, count, with_paths=True):
+        """The `count` highest-weight samples: (indices, unnormalised weights, rollouts [count][H][2] or None)."""
+        idx = np.empty(count, dtype=np.int32)
+        wts = np.empty(count)
+        xy = np.empty((count, self.H, 2)) if with_paths else None
+        self._check(self.lib.ccv_mppi_read_top_candidates(self._h, int(count), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                          capi.dptr(wts), capi.dptr(xy) if with_paths else None))
+        return idx, wts, xy
+
     def read_costs(self, first=0, count=None):
         count = self.K - first if count is None else count
         out = np.empty(count)

@@ -733,6 +733,48 @@ int ccv_mppi_read_candidates(ccv_mppi_handle* h, int32_t first, int32_t count, i
     return CCV_MPPI_OK;
 }
 
+int ccv_mppi_read_top_candidates(ccv_mppi_handle* h, int32_t count, int32_t* sample_out, double* weight_out, double* xy_out) {
+    if (!h || !sample_out || count < 0) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!h->have_weights) return fail(h, CCV_MPPI_ERR_STATE, "no weights yet");
+    if (count > h->K) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "count exceeds num_samples");
+    if (xy_out && (h->cfg.flags & CCV_MPPI_FLAG_NO_STATE_STORE)) return fail(h, CCV_MPPI_ERR_STATE, "state buffer disabled (NO_STATE_STORE)");
+    if (count == 0) return CCV_MPPI_OK;
+    // scratch: [count] indices (as 8-byte slots) | [count] weights | [count][H][2] states
+    const size_t n_xy = xy_out ? (size_t)count * h->H * 2 : 0;
+    int rc = ensure_scratch(h, ((size_t)count * 2 + n_xy) * sizeof(double));
+    if (rc) return rc;
+    int* d_idx = reinterpret_cast<int*>(h->d_scratch);
+    double* d_wsel = h->d_scratch + count;
+    double* d_xy = h->d_scratch + 2 * (size_t)count;
+    hipLaunchKernelGGL(k_top_weights, dim3(1), dim3(kTopBlock), 0, h->stream, h->d_w, h->K, count, d_idx, d_wsel);
+    HIP_TRY(h, hipGetLastError());
+    std::vector<int> idx(count);
+    std::vector<double> wsel(count);
+    HIP_TRY(h, hipMemcpyAsync(idx.data(), d_idx, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(wsel.data(), d_wsel, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // descending weight (NaN first), ties by sample index
+    std::vector<int> order(count);
+    for (int i = 0; i < count; ++i) order[i] = i;
+    auto key = [&](int i) { return (unsigned long long)*reinterpret_cast<const long long*>(&wsel[i]); };
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return key(a) != key(b) ? key(a) > key(b) : idx[a] < idx[b]; });
+    std::vector<int> sorted_idx(count);
+    for (int i = 0; i < count; ++i) {
+        sorted_idx[i] = idx[order[i]];
+        sample_out[i] = sorted_idx[i];
+        if (weight_out) weight_out[i] = wsel[order[i]];
+    }
+    if (xy_out) {
+        HIP_TRY(h, hipMemcpyAsync(d_idx, sorted_idx.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_gather_xy_list, dim3((count * h->H + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_xs, h->d_ys,
+                           h->pitch, h->H, d_idx, count, d_xy);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(xy_out, d_xy, n_xy * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return CCV_MPPI_OK;
+}
+
 static int check_range(ccv_mppi_handle* h, int32_t first, int32_t count, const void* out) {
     if (!h || !out || first < 0 || count < 0) return CCV_MPPI_ERR_INVALID_ARG;
     if ((int64_t)first + count > h->K) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "range exceeds num_samples");

@@ -109,6 +109,15 @@ std::vector<double> MPPIBase::candidate_path(int count, int stride) {
     return out;
 }
 
+std::vector<double> MPPIBase::best_candidate_paths(int count, std::vector<int32_t>* samples) {
+    // the `count` highest-weight samples of the last iteration, selected and gathered on the device
+    std::vector<double> out((size_t)count * horizon_ * 2);
+    std::vector<int32_t> idx((size_t)count);
+    last_status_ = ccv_mppi_read_top_candidates(handle_, count, idx.data(), nullptr, out.data());
+    if (samples) *samples = idx;
+    return out;
+}
+
 std::vector<double> MPPIBase::optimal_path() {
     // re-rolls the optimal controls through the plant model (dd:295-312)
     std::vector<double> out((size_t)(horizon_ - 1) * 3);

@@ -539,6 +539,101 @@ __global__ __launch_bounds__(kBlock) void k_gather_xy(const double* xs, const do
     out[(size_t)idx * 2 + 1] = ys[src];
 }
 
+// ---- top-N candidates by weight (publish_CandidatePath() feed, dd:265-294: at K = 65 536 rviz can only draw a few) ----
+// One workgroup.  Radix select on the weights' bit patterns (w >= 0, so the IEEE order is the integer order; NaN sorts
+// above everything and is reported first, as a reader of a NaN iteration should see): eight 8-bit passes find the N-th
+// largest key T and how many samples equal to T belong to the answer; a last pass writes the sample indices, "greater
+// than T" first and then the lowest-index "equal to T" ones -- positions come from block-wide prefix sums in index
+// order, so the output is the same on every run.  The host sorts the N pairs.
+constexpr int kTopBlock = 1024;
+__global__ __launch_bounds__(kTopBlock) void k_top_weights(const double* w, int K, int N, int* idx_out, double* w_out) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_remaining;
+    __shared__ int wsum[kTopBlock / 64][2];
+    __shared__ int s_base[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) {
+        s_prefix = 0ull;
+        s_remaining = N;
+    }
+    __syncthreads();
+    for (int pass = 7; pass >= 0; --pass) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        for (int i = tid; i < K; i += kTopBlock) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(w[i]);
+            const bool match = pass == 7 || (key >> (8 * (pass + 1))) == prefix;
+            if (match) atomicAdd(&hist[(unsigned int)(key >> (8 * pass)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int rem = s_remaining, b = 255;
+            for (; b > 0; --b) {
+                if ((int)hist[b] >= rem) break;
+                rem -= (int)hist[b];
+            }
+            s_remaining = rem;                 // how many of bin b (and, after the last pass, of key T) are still wanted
+            s_prefix = (prefix << 8) | (unsigned long long)b;
+        }
+        __syncthreads();
+    }
+    const unsigned long long T = s_prefix;
+    const int n_equal = s_remaining, n_greater = N - n_equal;
+    if (tid == 0) s_base[0] = s_base[1] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < K; i0 += kTopBlock) {
+        const int i = i0 + tid;
+        const unsigned long long key = i < K ? (unsigned long long)__double_as_longlong(w[i]) : 0ull;
+        const int fg = (i < K && key > T) ? 1 : 0, fe = (i < K && key == T) ? 1 : 0;
+        // exclusive prefix sums over the block in index order: wave ballots, then a scan of the 16 wave totals
+        const unsigned long long bg = __ballot(fg), be = __ballot(fe);
+        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        const int pg = __popcll(bg & below), pe = __popcll(be & below);
+        if (lane == 0) {
+            wsum[wv][0] = __popcll(bg);
+            wsum[wv][1] = __popcll(be);
+        }
+        __syncthreads();
+        int og = s_base[0], oe = s_base[1];
+        for (int j = 0; j < wv; ++j) {
+            og += wsum[j][0];
+            oe += wsum[j][1];
+        }
+        if (fg) {
+            idx_out[og + pg] = i;
+            w_out[og + pg] = w[i];
+        }
+        if (fe && oe + pe < n_equal) {
+            idx_out[n_greater + oe + pe] = i;
+            w_out[n_greater + oe + pe] = w[i];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tg = 0, te = 0;
+            for (int j = 0; j < kTopBlock / 64; ++j) {
+                tg += wsum[j][0];
+                te += wsum[j][1];
+            }
+            s_base[0] += tg;
+            s_base[1] += te;
+        }
+        __syncthreads();
+    }
+}
+
+// gather of listed samples: out[c][t] = (x, y) of sample idx[c] at step t
+__global__ __launch_bounds__(kBlock) void k_gather_xy_list(const double* xs, const double* ys, int pitch, int H, const int* idx,
+                                                           int count, double* out) {
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= count * H) return;
+    const int c = j / H, t = j % H;
+    const size_t src = (size_t)t * pitch + idx[c];
+    out[(size_t)j * 2 + 0] = xs[src];
+    out[(size_t)j * 2 + 1] = ys[src];
+}
+
 __global__ __launch_bounds__(kBlock) void k_normalise_weights(const double* w, const double* stats, int first, int count,
                                                              double* out) {
     const int i = blockIdx.x * kBlock + threadIdx.x;

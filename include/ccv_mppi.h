@@ -130,6 +130,11 @@ int ccv_mppi_update(ccv_mppi_handle* h, double* u_opt_out, ccv_mppi_stats* stats
 /* Feeds publish_CandidatePath() (dd:265-294) without a K x H device-to-host copy: samples first, first+stride, ...
  * (count of them); xy_out layout [count][H][2]. */
 int ccv_mppi_read_candidates(ccv_mppi_handle* h, int32_t first, int32_t count, int32_t stride, double* xy_out);
+/* The `count` samples with the largest weights of the last cost evaluation, in descending order of weight (ties: lower
+ * sample index first; NaN weights first): their indices, optionally their unnormalised weights [count] and their rollouts
+ * [count][H][2].  Selection (radix select) and gather run on the device; only the selected rows cross PCIe.  This is
+ * what publish_CandidatePath() (dd:265-294) can sensibly show of K = 65 536 candidates. */
+int ccv_mppi_read_top_candidates(ccv_mppi_handle* h, int32_t count, int32_t* sample_out, double* weight_out, double* xy_out);
 int ccv_mppi_read_costs(ccv_mppi_handle* h, int32_t first, int32_t count, double* out);
 /* normalised weights w_i / sum_w, i.e. the reference's weights_ (dd:222) */
 int ccv_mppi_read_weights(ccv_mppi_handle* h, int32_t first, int32_t count, double* out);

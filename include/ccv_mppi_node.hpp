@@ -72,6 +72,7 @@ public:
     ccv_mppi_stats last_stats_{};
     int last_status_ = CCV_MPPI_OK;
     std::vector<double> candidate_path(int count, int stride);   // publish_CandidatePath() feed (dd:265-294): [count][H][2]
+    std::vector<double> best_candidate_paths(int count, std::vector<int32_t>* samples = nullptr);   // same, the top-weight ones
     std::vector<double> optimal_path();                           // publish_OptimalPath() (dd:295-312): [H-1][3] x,y,yaw
 
     int horizon() const { return horizon_; }

@@ -400,6 +400,31 @@ def test_read_back_ranges_and_errors():
 # --------------------------------------------------------------------------------------------------------------
 # full BASELINE sizes: size-independent properties
 # --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wl,K,N", [("C2", 65536, 32), ("C2", 1000, 1000), ("C3", 4096, 1), ("C4", 2048, 100)])
+def test_top_candidates(wl, K, N):
+    """publish_CandidatePath() feed: the N highest-weight samples, selected on the device, against a host
+    sort of all weights; their rollouts against the strided read-back of the same samples."""
+    w = configs.workload(wl, num_samples=K)
+    p = w.params
+    path = helpers.oracle_path(w.path)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    g = MPPIController(p)
+    g.iterate(state, p.dt, xr, yr, yaw[0], 21, 2, want_stats=False)
+    wts = g.read_weights() * 1.0
+    idx, top_w, xy = g.read_top_candidates(N)
+    ref = np.lexsort((np.arange(K), -wts))[:N]          # descending weight, ties by index
+    np.testing.assert_array_equal(idx, ref)
+    # read_weights returns normalised weights, the top list unnormalised ones: same order, constant ratio
+    ratio = top_w / wts[idx]
+    assert np.allclose(ratio, ratio[0], rtol=1e-12)
+    for j in (0, N // 2, N - 1):
+        np.testing.assert_array_equal(xy[j], g.read_candidates(first=int(idx[j]), count=1)[0])
+    idx2, _, none = g.read_top_candidates(N, with_paths=False)
+    assert none is None
+    np.testing.assert_array_equal(idx2, idx)
+
+
 @pytest.mark.parametrize("wl", ["C2", "C3", "C4"])
 def test_full_size_properties(wl):
     w = configs.workload(wl)
