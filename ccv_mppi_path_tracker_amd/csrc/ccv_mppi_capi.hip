@@ -179,9 +179,9 @@ void fill_window(const ccv_mppi_handle* h, Window& W, const double* x0, const do
 // mode: MODE_FUSED / MODE_ROLLOUT / MODE_COST (mppi_rollout_coop.h)
 template <int MODEL>
 void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int mode) {
-    if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
+    if constexpr (MODEL != CCV_MPPI_FULL_BODY) {
     if (h->coop == 2) {
-        // three-wave kernel (mppi_rollout_r3.h); built for diff-drive only (see ccv_mppi_create)
+        // three-wave kernel (mppi_rollout_r3.h); not built for full body (see ccv_mppi_create)
         const dim3 cgrid((h->K + kPcSamples - 1) / kPcSamples), cblock(kR3Waves * 64);
         if (mode == MODE_FUSED && h->ev_kernel_start) {
             hipExtLaunchKernelGGL((k_rollout_r3<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, h->ev_kernel_start,
@@ -465,9 +465,10 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     h->lds_window = !(env && std::strcmp(env, "scalar") == 0);
     const char* kenv = getenv("CCV_MPPI_KERNEL");
     h->coop = !(kenv && std::strcmp(kenv, "v1") == 0) && h->lds_window;
-    // diff-drive: the three-wave kernel with a store wave (its LDS staging of the controls fits four workgroups per CU
-    // only for u_dim = 2); CCV_MPPI_KERNEL=pc / r3 force one or the other (experiments)
-    if (h->coop && h->cfg.model == CCV_MPPI_DIFF_DRIVE) h->coop = 2;
+    // diff-drive, steering: the three-wave kernel with a store wave.  Full body keeps the two-wave kernel: its producer
+    // needs 250 VGPR (three waves per SIMD allow 168) and its staging would not fit four workgroups per CU.
+    // CCV_MPPI_KERNEL=pc / r3 force one or the other where built (experiments)
+    if (h->coop && h->cfg.model != CCV_MPPI_FULL_BODY) h->coop = 2;
     if (h->coop && kenv && std::strcmp(kenv, "r3") == 0) h->coop = 2;
     if (h->coop && kenv && std::strcmp(kenv, "pc") == 0) h->coop = 1;
     h->prio_rotate = h->coop == 2 ? 1 : 0;   // measured: -4 us on the three-wave kernel, no gain on the two-wave one

@@ -65,6 +65,7 @@ struct PcShared {
     // kStage: the producer hands its controls and states to a store wave through LDS instead of storing them itself
     // (mppi_rollout_r3.h); here it stores them to HBM directly
     static constexpr bool kStage = false;
+    static constexpr bool kStageNoise = false;   // (with kStage) the fp32 normals are staged instead of the fp64 controls
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
     double c[kMaxH + 4];
     double p[2][kTU][2][kPcSamples];                       // (x,y) - pose of the 8 states of a block, double buffered
@@ -182,7 +183,8 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
                         }
                         u[d] = v;
                         if constexpr (SH::kStage) {
-                            sh.us[b & 1][nloc][lane] = v;
+                            if constexpr (SH::kStageNoise) sh.zs[b & 1][nloc][lane] = zq[q];
+                            else sh.us[b & 1][nloc][lane] = v;
                         } else {
 #if !defined(CCV_ABL_NO_STORE)
                             if (live) A.u[(size_t)n * pitch + k] = v;
@@ -327,7 +329,8 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
                 }
                 u[tt][d] = v;
                 if constexpr (SH::kStage) {
-                    sh.us[b & 1][nloc][lane] = v;
+                    if constexpr (SH::kStageNoise) sh.zs[b & 1][nloc][lane] = z[i];
+                    else sh.us[b & 1][nloc][lane] = v;
                 } else {
 #if !defined(CCV_ABL_NO_STORE)
                     // no `live` predicate: rows are padded to a multiple of 64 samples (pitch), lanes past K write their

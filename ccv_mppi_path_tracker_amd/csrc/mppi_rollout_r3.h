@@ -25,16 +25,21 @@ constexpr int kR3Waves = 3;
 constexpr int kR3CStates = 8;
 constexpr int kR3RB = 12;   // rows per LDS transpose batch in the epilogue: 3 waves x 12 x 65 doubles fit p + ab + c
 
+// u_dim = 2: the fp64 controls of a block are staged (2 x 8 KB).  u_dim = 3: four workgroups per CU only fit if the
+// fp32 normals are staged instead (2 x 6 KB) -- the store wave then forms u = clamp(z * sigma + u*) a second time, with
+// the producer's arithmetic (it has the issue slots to spare).
 template <int MODEL>
 struct R3Shared {
     static constexpr bool kStage = true;
+    static constexpr bool kStageNoise = udim_of(MODEL) > 2;
     // (p, ab, c are contiguous and are reused as the epilogue's transpose buffers)
     double p[2][kTU][2][kPcSamples];                       // absolute (x,y) of the 8 states of a block, double buffered
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
     double c[kMaxH + 4];
     double cost[kR3Waves][kPcSamples];
     alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u*
-    double us[2][kTU * udim_of(MODEL)][kPcSamples];        // clamped controls of a block, double buffered
+    double us[kStageNoise ? 1 : 2][kStageNoise ? 1 : kTU * udim_of(MODEL)][kPcSamples];   // clamped controls of a block, double buffered
+    float zs[kStageNoise ? 2 : 1][kStageNoise ? kTU * udim_of(MODEL) : 1][kPcSamples];    // or their normals
 };
 
 template <int MODEL, int MODE>
@@ -140,11 +145,24 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
 #if !defined(CCV_ABL_NO_STORE)
                 if constexpr (MODE == MODE_FUSED) {
                     const int nrows = min(kTU, H - 1 - t0) * UD;   // control steps t < H-1
-#pragma unroll
-                    for (int r = 0; r < kTU * UD; ++r) {
+                    static_for<kTU * UD>([&](auto RR) {
+                        constexpr int r = decltype(RR)::value;
                         // rows are padded to a multiple of 64 samples (pitch): lanes past K write their padding slot
-                        if (r < nrows) A.u[(size_t)(t0 * UD + r) * pitch + k] = sh.us[b & 1][r][lane];
-                    }
+                        if (r < nrows) {
+                            double v;
+                            if constexpr (R3Shared<MODEL>::kStageNoise) {
+                                constexpr int d = r % UD;
+                                v = (double)sh.zs[b & 1][r][lane] * A.sigma + sh.nom[t0 * UD + r];   // as pc_produce*
+                                v = clampd(v, arg5<d>(A.umin), arg5<d>(A.umax));
+                                if constexpr (FB && d == 2) {
+                                    if (A.steer_off) v = 0.0;
+                                }
+                            } else {
+                                v = sh.us[b & 1][r][lane];
+                            }
+                            A.u[(size_t)(t0 * UD + r) * pitch + k] = v;
+                        }
+                    });
                 }
                 if constexpr (MODE != MODE_COST) {
                     if (A.store_xy) {
