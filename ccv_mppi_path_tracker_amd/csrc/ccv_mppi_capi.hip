@@ -12,12 +12,8 @@
 #include <vector>
 
 #include "mppi_kernels.h"
-#if defined(CCV_USE_RR)
-#include "experimental/mppi_rollout_rr.h"   // A/B experiments only (tools/ablate.py)
-#else
 #include "mppi_rollout_pc.h"
 #include "mppi_rollout_r3.h"
-#endif
 
 using namespace ccv;
 
