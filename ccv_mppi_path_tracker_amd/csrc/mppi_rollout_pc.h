@@ -1,4 +1,6 @@
-// k_rollout_pc: the production sample + rollout + cost kernel ("producer / consumer" time blocks).
+// k_rollout_pc: the two-wave sample + rollout + cost kernel ("producer / consumer" time blocks) -- the production kernel
+// of the full-body model -- and the building blocks (pc_produce*, pc_consume, pc_reduce_rows, ...) it shares with the
+// three-wave kernel of the diff-drive and steering models (mppi_rollout_r3.h).
 //
 // One sample per lane.  A workgroup is TWO waves that own the same 64 samples and alternate roles over time blocks
 // of kTU = 8 steps:
