@@ -241,6 +241,8 @@ bool fast_trig_safe(const ccv_mppi_handle* h, const RolloutArgs& A, int mode) {
         bound = std::fmax(bound, std::fabs(A.x0[3]) + steps * umax[3]);
         bound = std::fmax(bound, std::fabs(A.x0[4]) + steps * umax[4]);
     }
+    // diff drive advances (sin, cos) of the heading by the step's turn angle: needs |w| dt <= pi/4 (fast_trig.h)
+    if (h->cfg.model == CCV_MPPI_DIFF_DRIVE && !(umax[1] * std::fabs(A.dt) <= kSmallTurnLimit)) return false;
     return bound <= kFastTrigLimit;   // false for NaN
 }
 

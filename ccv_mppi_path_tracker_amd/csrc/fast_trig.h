@@ -98,4 +98,40 @@ __device__ __forceinline__ void fast_sincos_n(const double (&x)[N], double (&s)[
     }
 }
 
+// sin and cos of N small angles |r| <= pi/4: the kernel polynomials of fast_sincos without range reduction and quadrant
+// logic, stage by stage.  Used to ADVANCE a heading's (sin, cos) by the step's turn angle instead of evaluating them from
+// the accumulated heading: (s, c) <- (s cos d + c sin d, c cos d - s sin d).
+constexpr double kSmallTurnLimit = 7.85398163397448279e-01;   // pi/4
+template <int N>
+__device__ __forceinline__ void kernel_sincos_n(const double (&r)[N], double (&s)[N], double (&c)[N]) {
+    double z[N], ps[N], pc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = r[i] * r[i];
+    CCV_KEEP_ORDER();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ps[i] = fma(z[i], 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+        pc[i] = fma(z[i], -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    }
+    CCV_KEEP_ORDER();
+#define CCV_STAGE2(cs_, cc_)                                         \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) {                  \
+        ps[i] = fma(z[i], ps[i], cs_);                               \
+        pc[i] = fma(z[i], pc[i], cc_);                               \
+    }                                                                \
+    CCV_KEEP_ORDER();
+    CCV_STAGE2(2.75573137070700676789e-06, -2.75573143513906633035e-07)
+    CCV_STAGE2(-1.98412698298579493134e-04, 2.48015872894767294178e-05)
+    CCV_STAGE2(8.33333333332248946124e-03, -1.38888888888741095749e-03)
+    CCV_STAGE2(-1.66666666666666324348e-01, 4.16666666666666019037e-02)
+#undef CCV_STAGE2
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        s[i] = fma(z[i] * r[i], ps[i], r[i]);
+        const double hz = 0.5 * z[i];
+        const double w = 1.0 - hz;
+        c[i] = w + (((1.0 - w) - hz) + z[i] * (z[i] * pc[i]));
+    }
+}
+
 }  // namespace ccv

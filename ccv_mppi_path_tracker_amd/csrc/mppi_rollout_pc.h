@@ -58,9 +58,10 @@ struct PcState {
     double x, y, yaw;
     double roll, pitch;                                 // full body only
     double p_v, p_rv, p_sdir, p_cdir, p_c2, p_c3, p_ac;  // full body: step t-1 quantities for the ZMP term (fb:468-486)
+    double sn, cs;                                      // diff drive: sin / cos of yaw, advanced by rotation (pc_produce_batched)
 };
 template <int MODEL>
-constexpr int kPcStateWords = MODEL == CCV_MPPI_FULL_BODY ? 12 : 3;
+constexpr int kPcStateWords = MODEL == CCV_MPPI_FULL_BODY ? 12 : (MODEL == CCV_MPPI_DIFF_DRIVE ? 5 : 3);
 
 template <int MODEL>
 struct PcShared {
@@ -373,13 +374,35 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
         if constexpr (MODEL != CCV_MPPI_DIFF_DRIVE) hd[tt] = yawv[tt] + u[tt][2];
     }
     CCV_STAMP_AT(ST, 1);
-    // ---- 3. sin/cos of the 8 headings: independent chains, evaluated stage by stage in two groups of four
+    // ---- 3. sin/cos of the 8 headings
     double sn[kTU], cs[kTU];
 #if defined(CCV_ABL_NO_SINCOS)
 #pragma unroll
     for (int tt = 0; tt < kTU; ++tt) { sn[tt] = hd[tt] * 0.5; cs[tt] = 1.0 - hd[tt] * 0.25; }
 #else
-    {
+    if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
+        // diff drive: the heading only ever changes by the step's turn w*dt, so its (sin, cos) are ADVANCED by that angle --
+        // eight short independent polynomial pairs (no range reduction, no quadrant logic: the host admits this kernel
+        // only for |w| dt <= pi/4) and a chain of eight 2x2 rotations, ~25 fp64 operations per step instead of ~40.
+        // Rounding differs from sin(yaw) / cos(yaw) of the accumulated yaw by a few ulp per step.
+        double turn[kTU], sd[kTU], cd[kTU];
+#pragma unroll
+        for (int tt = 0; tt < kTU; ++tt) turn[tt] = u[tt][1] * dt;
+        kernel_sincos_n<kTU>(turn, sd, cd);
+        double s_ = S.sn, c_ = S.cs;
+#pragma unroll
+        for (int tt = 0; tt < kTU; ++tt) {
+            sn[tt] = s_;
+            cs[tt] = c_;
+            const double s2 = fma(s_, cd[tt], c_ * sd[tt]);
+            const double c2 = fma(c_, cd[tt], -(s_ * sd[tt]));
+            s_ = s2;
+            c_ = c2;
+        }
+        S.sn = s_;
+        S.cs = c_;
+    } else {
+        // independent chains, evaluated stage by stage in two groups of four
         constexpr int SG = 4;
 #pragma unroll
         for (int g = 0; g < kTU / SG; ++g) {
@@ -692,11 +715,16 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
                 S.pitch = A.x0[4];
                 S.p_v = S.p_rv = S.p_sdir = S.p_c2 = S.p_c3 = S.p_ac = 0.0;
                 S.p_cdir = 1.0;
+                fast_sincos(A.x0[2], S.sn, S.cs);
             } else {
                 const double(*st)[kPcSamples] = sh.st[(s - 1) & 1];
                 S.x = st[0][lane];
                 S.y = st[1][lane];
                 S.yaw = st[2][lane];
+                if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
+                    S.sn = st[3][lane];
+                    S.cs = st[4][lane];
+                }
                 if constexpr (FB) {
                     S.roll = st[3][lane];
                     S.pitch = st[4][lane];
@@ -720,6 +748,10 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
             st[0][lane] = S.x;
             st[1][lane] = S.y;
             st[2][lane] = S.yaw;
+            if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
+                st[3][lane] = S.sn;
+                st[4][lane] = S.cs;
+            }
             if constexpr (FB) {
                 st[3][lane] = S.roll;
                 st[4][lane] = S.pitch;

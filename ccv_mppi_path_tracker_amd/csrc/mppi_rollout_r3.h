@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
         S.pitch = A.x0[4];
         S.p_v = S.p_rv = S.p_sdir = S.p_c2 = S.p_c3 = S.p_ac = 0.0;
         S.p_cdir = 1.0;
+        fast_sincos(A.x0[2], S.sn, S.cs);
 #if defined(CCV_STAMP)
         PcStamps ST;   // (diagnostic builds: the producer's stamp slots are not read back for this kernel)
         for (int i = 0; i < 8; ++i) ST.acc[i] = 0;

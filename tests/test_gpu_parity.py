@@ -338,6 +338,25 @@ def test_huge_heading_takes_the_libm_path(model):
     assert np.max(np.abs(c_g - c_o) / c_o) < TOL_COST
 
 
+@pytest.mark.parametrize("dt", [0.1, 0.39, 0.4, 1.0])
+def test_diff_drive_turn_per_step_gate(dt):
+    """Diff drive advances (sin, cos) of the heading by the step's turn angle w*dt with short polynomials valid for
+    |w| dt <= pi/4 (csrc/fast_trig.h: kernel_sincos_n); the host checks the bound per call and otherwise uses the plain
+    kernel (w_max = 2 rad/s: the switch is at dt = 0.3927).  Either way the oracle's sin(yaw), cos(yaw) are matched."""
+    p = configs.diff_drive_defaults(320, 50).with_(dt=dt)
+    path = helpers.oracle_path("sinusoid")
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    for it in range(2):
+        u_o = o.iterate(state, p.dt, xr, yr, yaw[0], seed=8, rng="philox", iteration=it)
+        u_g, st = g.iterate(state, p.dt, xr, yr, yaw[0], 8, it)
+    assert np.max(np.abs(g.read_costs() - o.costs()) / o.costs()) < TOL_COST
+    assert helpers.rel_err(u_g, u_o) < 1e-8
+    xs_o = np.stack([o.states("x"), o.states("y")], axis=-1)
+    np.testing.assert_allclose(g.read_candidates(), xs_o, rtol=1e-11, atol=1e-11)
+
+
 def test_nan_pose_propagates_like_the_reference():
     """No NaN guard anywhere in the reference: a NaN pose makes every cost, weight and control NaN."""
     p = configs.diff_drive_defaults(128, 12)
