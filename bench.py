@@ -210,7 +210,7 @@ def main():
                        "state_store": not args.no_state_store},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_rollout_r3" if p.model == "diff_drive" else "k_rollout_pc",
+                         "kernel": "k_rollout_pc" if p.model == "full_body" else "k_rollout_r3",
                          "kernel_avg_us": 1e6 * roll_avg_s,
                          "algorithmic_bytes_per_launch": B_roll * k_local,
                          "iteration_avg_us": 1e6 * iter_avg_s,

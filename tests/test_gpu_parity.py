@@ -357,6 +357,36 @@ def test_diff_drive_turn_per_step_gate(dt):
     np.testing.assert_allclose(g.read_candidates(), xs_o, rtol=1e-11, atol=1e-11)
 
 
+@pytest.mark.parametrize("kind", ["random", "circle", "duplicates", "far", "line_behind"])
+def test_window_pruning_is_exact_on_awkward_windows(kind):
+    """Diff drive skips window points that cannot be the nearest one for any sample of a wave (pc_consume: bounds of the
+    linear form over the wave's bounding box, then the hull of the surviving indices).  The argument does not assume a
+    path-like window: windows that are unordered, closed, degenerate or far away must give the oracle's costs too."""
+    p = configs.diff_drive_defaults(512, 50)
+    rng = np.random.default_rng(3)
+    H = p.horizon
+    state = np.array([0.4, -0.3, 0.7])
+    if kind == "random":
+        xr, yr = rng.uniform(-3, 3, H), rng.uniform(-3, 3, H)
+    elif kind == "circle":
+        a = np.linspace(0, 2 * np.pi, H, endpoint=False)
+        xr, yr = state[0] + 1.5 * np.cos(a), state[1] + 1.5 * np.sin(a)
+    elif kind == "duplicates":
+        xr, yr = np.full(H, 1.0), np.full(H, 0.5)
+        xr[::7] += 0.8
+    elif kind == "far":
+        xr, yr = np.linspace(150.0, 160.0, H), np.linspace(-90.0, -80.0, H)     # beyond the 100 m gate for most samples
+    else:
+        xr, yr = state[0] - np.linspace(0.0, 4.0, H), np.full(H, state[1] + 0.2)  # a line behind the robot
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    for it in range(1 if kind == "far" else 3):   # (far: every weight underflows, the next warm start is NaN -- SURVEY Q4)
+        u_o = o.iterate(state, p.dt, xr, yr, 0.0, seed=4, rng="philox", iteration=it)
+        u_g, st = g.iterate(state, p.dt, xr, yr, 0.0, 4, it)
+        assert np.max(np.abs(g.read_costs() - o.costs()) / o.costs()) < TOL_COST
+    if kind != "far":
+        assert helpers.rel_err(u_g, u_o) < 1e-8
+
+
 def test_nan_pose_propagates_like_the_reference():
     """No NaN guard anywhere in the reference: a NaN pose makes every cost, weight and control NaN."""
     p = configs.diff_drive_defaults(128, 12)
