@@ -121,10 +121,18 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    # (rehearsal of the N > 1 path on a one-GPU box: CCV_BENCH_DEVICE=0 puts every rank on device 0 and
+    #  CCV_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device; never the reported configuration)
+    if "CCV_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["CCV_BENCH_DEVICE"])
+    backend = os.environ.get("CCV_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     w = configs.workload(args.workload)
     p = w.params
@@ -157,8 +165,9 @@ def main():
     # Set-up, not part of the warm-up count: for the first several hundred launches of a process the host side of a
     # launch is several times slower on some boxes (runtime pools growing, host and device clocks ramping; measured with
     # tools/host_cost.py: 120 us/call for the first ~600 calls, 12 us afterwards).  Run until half a second has passed.
+    # (N > 1: every step is a collective, so all ranks must run the same number -- fixed count, no clock)
     t_prime, n_prime = time.perf_counter(), 0
-    while time.perf_counter() - t_prime < 0.5 or n_prime < 1024:
+    while (n_prime < 4096) if world > 1 else (time.perf_counter() - t_prime < 0.5 or n_prime < 1024):
         for _ in range(128):
             step(n_prime)
             n_prime += 1
