@@ -509,7 +509,8 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
 // ---------------------------------------------------------------------------------------------------------------
 template <int NV, int MODEL, class SH>
 __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, double& cost, const int b, const int lane,
-                                           const int i0 = 0) {   // states i0 .. i0+NV-1 of block b
+                                           const int i0 = 0,          // states i0 .. i0+NV-1 of block b
+                                           int* prune_on = nullptr) {  // wave-uniform switch of the window pruning (below)
     const int H4 = (A.H + 3) & ~3;   // the window is padded with c = +inf: four points per iteration, no remainder
     double px[NV], py[NV], m[NV];
 #pragma unroll
@@ -558,9 +559,11 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
     // remain (diff drive), 38-49 % (full body).  Measured (same box, kernel us): diff drive 50.7 -> 46.7; steering
     // 60.4 -> 63.1 and full body 402 -> 401, where the producer, not this loop, is the workgroup's critical chain and the
     // ~200 extra instructions only add contention -- so it is compiled in for diff drive only.
+    // The test costs ~600 cycles per block; the samples of a wave fan out with time, so once a block keeps more than 3/4 of
+    // the window the later ones will too and the wave stops testing (*prune_on = 0) for the rest of the launch.
     int jb = 0, je = H4;
 #if !defined(CCV_EXP_NO_PRUNE)
-    if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
+    if (MODEL == CCV_MPPI_DIFF_DRIVE && (prune_on == nullptr || *prune_on)) {
         double xlo = px[0], xhi = px[0], ylo = py[0], yhi = py[0];
 #pragma unroll
         for (int i = 1; i < NV; ++i) {
@@ -607,6 +610,7 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
             jb = lo & ~3;
             je = (hi | 3) + 1;
         }
+        if (prune_on && 4 * (je - jb) > 3 * H4) *prune_on = 0;
     }
 #endif
     fetch(ab0, c0, jb);

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
         }
     } else if (wv == 1) {
         // ---------------- distance wave: the first kR3CStates states of block s-1
+        int prune_on = 1;
         for (int s = 0; s <= nblocks; ++s) {
             pc_rotate_priority(A, s);
             if constexpr (COST) {
@@ -121,14 +122,14 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
                     const int b = s - 1;
                     const int nv = min(kR3CStates, nstates - b * kTU);
                     switch (nv) {
-                        case 8: pc_consume<8, MODEL>(A, sh, cost, b, lane); break;
-                        case 7: pc_consume<7, MODEL>(A, sh, cost, b, lane); break;
-                        case 6: pc_consume<6, MODEL>(A, sh, cost, b, lane); break;
-                        case 5: pc_consume<5, MODEL>(A, sh, cost, b, lane); break;
-                        case 4: pc_consume<4, MODEL>(A, sh, cost, b, lane); break;
-                        case 3: pc_consume<3, MODEL>(A, sh, cost, b, lane); break;
-                        case 2: pc_consume<2, MODEL>(A, sh, cost, b, lane); break;
-                        case 1: pc_consume<1, MODEL>(A, sh, cost, b, lane); break;
+                        case 8: pc_consume<8, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 7: pc_consume<7, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 6: pc_consume<6, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 5: pc_consume<5, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 4: pc_consume<4, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 3: pc_consume<3, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 2: pc_consume<2, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 1: pc_consume<1, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
                         default: break;
                     }
                 }
