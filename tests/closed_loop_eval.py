@@ -5,7 +5,9 @@ the RMS of the distance from each logged pose to the nearest path point.  Here b
 Philox noise) drive the same kinematic plant (the Euler model the controller itself assumes) along the sinusoid of
 launch/diff_drive_mppi.launch and the dkan path for `steps` control periods.
 
-  python tools/closed_loop_eval.py [--steps 150] [--samples 2048]        (needs a GPU; the oracle runs on the host)
+  python tests/closed_loop_eval.py [--steps 150] [--samples 2048]        (needs a GPU; the oracle runs on the host)
+
+Lives under tests/ because it runs the oracle (test infrastructure) as the checker; not collected by pytest.
 """
 import argparse
 import os
@@ -15,7 +17,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # helpers.py
 import ccv_mppi_path_tracker_amd as amd  # noqa: E402
 from ccv_mppi_path_tracker_amd import configs  # noqa: E402
 import helpers  # noqa: E402  (tests/helpers.py: oracle construction, test infrastructure)
