@@ -172,7 +172,7 @@ void fill_window(const ccv_mppi_handle* h, Window& W, const double* x0, const do
     }
 }
 
-// mode: MODE_FUSED / MODE_ROLLOUT / MODE_COST (mppi_rollout_coop.h)
+// mode: MODE_FUSED / MODE_ROLLOUT / MODE_COST (mppi_rollout_pc.h)
 template <int MODEL>
 void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int mode) {
     if constexpr (MODEL != CCV_MPPI_FULL_BODY) {

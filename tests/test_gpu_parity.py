@@ -180,7 +180,7 @@ def test_fused_equals_stagewise_bitwise(name):
 
 @pytest.mark.parametrize("name", ["dd_K256_H50_sinusoid_C2", "sd_K256_H50_sinusoid_C3", "fb_K128_H80_dkan_C4"])
 def test_kernel_variants_agree(monkeypatch, name):
-    """The production kernel (4 waves share 64 samples) against the plain one-sample-per-lane variants kept for
+    """The production kernels (two or three waves share 64 samples) against the plain one-sample-per-lane variants kept for
     experiments (CCV_MPPI_KERNEL=v1, LDS or scalar-load window): same samples, costs equal up to summation order."""
     p, kind = CASES[name]
     path = helpers.oracle_path(kind)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (never shipped): per-phase cycle shares of k_rollout_coop from a -DCCV_STAMP build (_abl/lib_stamp.so).
+"""Diagnostic (never shipped): per-phase cycle shares and workgroup timelines of the rollout kernels from a -DCCV_STAMP build (_abl/lib_stamp.so).
 Run on the GPU box:  python tools/stamps.py [K]"""
 import ctypes as C
 import os
