@@ -42,6 +42,21 @@ struct R3Shared {
     float zs[kStageNoise ? 2 : 1][kStageNoise ? kTU * udim_of(MODEL) : 1][kPcSamples];    // or their normals
 };
 
+// First chunk of the epilogue's re-read for this kernel's row dealing (units of kR3RB rows, wave w owns units w, w+3, ...):
+// with the row of load i a compile-time distance from the wave's first row, an address costs one scalar multiply and
+// one vector add instead of the ~12 scalar instructions of the generic clamped form (60 loads per wave: ~1.3 us).
+__device__ __forceinline__ void r3_update_fetch0(const RolloutArgs& A, double (&v)[kUpdCH], const int wv, const int mcount,
+                                                 const int kk) {
+    const size_t pitch = (size_t)A.pitch;
+    const double* p0 = A.u + kk + (size_t)(wv * kR3RB) * pitch;
+#pragma unroll
+    for (int i = 0; i < kUpdCH; ++i) {
+        const size_t rows_ahead = (size_t)((i / kR3RB) * (kR3Waves * kR3RB) + i % kR3RB);   // constant after unrolling
+        v[i] = 0.0;
+        if (i < mcount) v[i] = p0[rows_ahead * pitch];
+    }
+}
+
 template <int MODEL, int MODE>
 __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutArgs A, const Window W) {
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
@@ -219,7 +234,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
         const Rows rows{R, wv};
         const int mcount = A.fuse_update ? rows.count() : 0;
         // start the re-read of this wave's share of the controls before anything else (see pc_update_fetch)
-        if (mcount > 0) pc_update_fetch(A, upd, rows, 0, mcount, kk);
+        if (mcount > 0) r3_update_fetch0(A, upd, wv, mcount, kk);
         sh.cost[wv][lane] = cost;
         pc_barrier_lds();
         const double total = (sh.cost[0][lane] + sh.cost[1][lane]) + sh.cost[2][lane];
