@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Soak / race screen (run by hand on a GPU box, not collected by pytest): the same scripted closed-loop-like sequence of
+iterations twice on fresh handles; warm start, costs and candidate states must come out bit-identical.  Any race in the
+LDS hand-offs, the store wave or the deferred division would show as a difference after thousands of launches.
+  python tests/soak_determinism.py [iterations]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ccv_mppi_path_tracker_amd as amd  # noqa: E402
+from ccv_mppi_path_tracker_amd import configs  # noqa: E402
+import bench  # noqa: E402
+
+n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+ok = True
+for wl, K in (("C2", 65536), ("C3", 65536), ("C4", 32768), ("C2", 1000)):
+    w = configs.workload(wl, num_samples=K)
+    p = w.params
+    inputs = bench.script_inputs(amd, w, 64)
+    res = []
+    for rep in range(2):
+        g = amd.MPPIController(p)
+        for it in range(n_it):
+            s, xr, yr, yaw0 = inputs[it % len(inputs)]
+            g.iterate_enqueue(s, p.dt, xr, yr, yaw0, 77, it)
+        g.synchronize()
+        res.append((g.get_nominal().copy(), g.read_costs().copy(), g.read_candidates(0, 64, max(1, K // 64)).copy()))
+        g.close()
+    same = all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
+    finite = bool(np.all(np.isfinite(res[0][0])))
+    print("%s K=%d: %d iterations twice: bit-identical %s, finite %s" % (wl, K, n_it, same, finite))
+    ok = ok and same and finite
+sys.exit(0 if ok else 1)
