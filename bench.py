@@ -205,8 +205,9 @@ def main():
         achieved = B_roll * k_local / roll_avg_s / 1e9 if roll_avg_s > 0 else None
         traffic = latest_pmc_traffic(args.workload) if world == 1 else None
         out = {
-            "metric": "trajectory rollouts/s (K x iters/s), diff-drive T=50" if args.workload == "C2"
-                      else "trajectory rollouts/s (K x iters/s)",
+            # BASELINE.json's metric string; `value` is its first component, `ms_per_step` the second (ms per MPPI iteration)
+            "metric": "trajectory rollouts/s (K\u00d7iters/s) + ms/MPPI-iteration, diff-drive T=50" if args.workload == "C2"
+                      else "trajectory rollouts/s (K\u00d7iters/s) + ms/MPPI-iteration",
             "value": k_total * args.steps / elapsed,
             "unit": "rollouts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
