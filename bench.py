@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C2", help="C2 (headline) | C3 | C4")
     ap.add_argument("--samples-per-gpu", type=int, default=None)
+    ap.add_argument("--path", default=None, help="reference path instead of the workload's: straight | sinusoid | dkan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-state-store", action="store_true", help="skip the KxH x,y buffer (not the headline)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel hipEvents in the timed region")
@@ -135,6 +136,9 @@ def main():
             dist.init_process_group(backend)
 
     w = configs.workload(args.workload)
+    if args.path:
+        import dataclasses
+        w = dataclasses.replace(w, path=args.path, description=w.description.replace(w.path, args.path))
     p = w.params
     k_local = args.samples_per_gpu or p.num_samples
     k_total = k_local * world
