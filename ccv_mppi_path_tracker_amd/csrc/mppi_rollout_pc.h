@@ -72,7 +72,9 @@ struct PcShared {
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
     double c[kMaxH + 4];
     double p[2][kTU][2][kPcSamples];                       // (x,y) - pose of the 8 states of a block, double buffered
-    double st[2][kPcStateWords<MODEL>][kPcSamples];        // producer -> next producer
+    // producer -> next producer.  One buffer is enough: the producer of block s reads it first thing and writes it last,
+    // the other wave reads it only after the barrier that ends the step
+    double st[kPcStateWords<MODEL>][kPcSamples];
     double cost[kPcWaves][kPcSamples];
     alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u* (see pc_stage_nominal)
 };
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
                 S.p_cdir = 1.0;
                 fast_sincos(A.x0[2], S.sn, S.cs);
             } else {
-                const double(*st)[kPcSamples] = sh.st[(s - 1) & 1];
+                const double(*st)[kPcSamples] = sh.st;
                 S.x = st[0][lane];
                 S.y = st[1][lane];
                 S.yaw = st[2][lane];
@@ -808,7 +810,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
 #endif
                                                                               );
             if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, s, lane, k, kk, live, kg);
-            double(*st)[kPcSamples] = sh.st[s & 1];
+            double(*st)[kPcSamples] = sh.st;
             st[0][lane] = S.x;
             st[1][lane] = S.y;
             st[2][lane] = S.yaw;
