@@ -77,6 +77,8 @@ struct PcShared {
     double st[kPcStateWords<MODEL>][kPcSamples];
     double cost[kPcWaves][kPcSamples];
     alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u* (see pc_stage_nominal)
+    // full body: normals made ahead by each wave for the block it produces next (pc_noise_ahead)
+    float ahead[MODEL == CCV_MPPI_FULL_BODY ? kPcWaves : 1][MODEL == CCV_MPPI_FULL_BODY ? 16 : 1][kPcSamples];
 };
 
 // The warm start u* is staged in LDS once per workgroup.  Read straight from memory inside the time loop (scalar or
@@ -259,6 +261,55 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
     });
 }
 
+// The 4*CN normals of Philox calls C0 .. C0+CN-1 of time block b (call c holds normals 4c .. 4c+3 of the block): CN Philox
+// blocks with their rounds interleaved, then the 2*CN Box-Muller pairs stage by stage.
+template <int MODEL, int C0, int CN>
+__device__ __forceinline__ void pc_block_normals(const RolloutArgs& A, const int b, const uint32_t kg, float (&z)[4 * CN]) {
+    constexpr int UD = udim_of(MODEL);
+#if defined(CCV_ABL_NO_NOISE)
+#pragma unroll
+    for (int i = 0; i < 4 * CN; ++i) z[i] = (float)(kg & 1023u) * 1e-3f - 0.5f;
+#else
+    uint32_t c0[CN], c1[CN], c2[CN], c3[CN];
+#pragma unroll
+    for (int i = 0; i < CN; ++i) {
+        c0[i] = kg;
+        c1[i] = (uint32_t)((b * kTU * UD) >> 2) + (uint32_t)(C0 + i);
+        c2[i] = A.iter_lo;
+        c3[i] = A.iter_hi;
+    }
+    philox4x32_10_n<CN>(c0, c1, c2, c3, A.seed_lo, A.seed_hi);
+    uint32_t ba[2 * CN], bb[2 * CN];
+    float z0[2 * CN], z1[2 * CN];
+#pragma unroll
+    for (int i = 0; i < CN; ++i) {
+        ba[2 * i] = c0[i];
+        bb[2 * i] = c1[i];
+        ba[2 * i + 1] = c2[i];
+        bb[2 * i + 1] = c3[i];
+    }
+    box_muller_f32_n<2 * CN>(ba, bb, z0, z1);
+#pragma unroll
+    for (int i = 0; i < 2 * CN; ++i) {
+        z[2 * i] = z0[i];
+        z[2 * i + 1] = z1[i];
+    }
+#endif
+}
+
+// Full body, two-wave kernel: the producer (10 Philox calls, 20 Box-Muller pairs, 32 sin/cos per block) takes 1.5x as
+// long as the distance phase of its partner, which then idles.  The partner therefore makes the first kPcAheadCalls
+// Philox calls' normals of the block IT will produce next and parks them in LDS (its own slot: no synchronisation).
+constexpr int kPcAheadCalls = 4;
+template <int MODEL>
+__device__ __forceinline__ void pc_noise_ahead(const RolloutArgs& A, float (*slot)[kPcSamples], const int b, const int lane,
+                                               const uint32_t kg) {
+    float z[4 * kPcAheadCalls];
+    pc_block_normals<MODEL, 0, kPcAheadCalls>(A, b, kg, z);
+#pragma unroll
+    for (int i = 0; i < 4 * kPcAheadCalls; ++i) slot[i][lane] = z[i];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // producer, fast path for a block whose 8 steps all carry controls: the same arithmetic as pc_produce, arranged in
 // batches so that the independent chains of the 8 steps (Philox rounds, Box-Muller, sin/cos) sit in ONE basic block and
@@ -271,6 +322,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
 #if defined(CCV_STAMP)
                                                    , PcStamps& ST
 #endif
+                                                   , const float (*ahead)[kPcSamples] = nullptr   // pc_noise_ahead's slot
                                                    ) {
     constexpr int UD = udim_of(MODEL);
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
@@ -283,48 +335,24 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
     // ---- 1. controls of the 8 steps
     double u[kTU][UD];
     if constexpr (MODE == MODE_FUSED) {
-        // Philox blocks in groups of PG with their rounds interleaved, then the 2*PG Box-Muller pairs stage by stage
-        constexpr int PG = NCALL <= 4 ? NCALL : NCALL / 2;
-        static_assert(NCALL % PG == 0, "group size");
-        static_for<NCALL / PG>([&](auto GG) {
-            constexpr int g = decltype(GG)::value;
-            float z[4 * PG];
-            double nomv[4 * PG];   // warm start u* of this group from LDS (broadcast reads), in flight under the Philox rounds
+        // Philox calls in groups (rounds interleaved within a group, then the group's Box-Muller pairs stage by stage):
+        // 4 | 3+3 | 5+5, or for full body 4 (possibly made ahead by the partner wave) + 3 + 3
+        auto group = [&](auto C0_, auto CN_, const bool from_lds) {
+            constexpr int C0 = decltype(C0_)::value, CN = decltype(CN_)::value;
+            float z[4 * CN];
+            double nomv[4 * CN];   // warm start u* of this group from LDS (broadcast reads), in flight under the Philox rounds
 #pragma unroll
-            for (int i = 0; i < 4 * PG; ++i) nomv[i] = sh.nom[t0 * UD + 4 * g * PG + i];
+            for (int i = 0; i < 4 * CN; ++i) nomv[i] = sh.nom[t0 * UD + 4 * C0 + i];
             CCV_KEEP_ORDER();
-#if defined(CCV_ABL_NO_NOISE)
+            if (from_lds) {
 #pragma unroll
-            for (int i = 0; i < 4 * PG; ++i) z[i] = (float)(kg & 1023u) * 1e-3f - 0.5f;
-#else
-            uint32_t c0[PG], c1[PG], c2[PG], c3[PG];
-#pragma unroll
-            for (int i = 0; i < PG; ++i) {
-                c0[i] = kg;
-                c1[i] = (uint32_t)((t0 * UD) >> 2) + (uint32_t)(g * PG + i);
-                c2[i] = A.iter_lo;
-                c3[i] = A.iter_hi;
+                for (int i = 0; i < 4 * CN; ++i) z[i] = ahead[4 * C0 + i][lane];
+            } else {
+                pc_block_normals<MODEL, C0, CN>(A, b, kg, z);
             }
-            philox4x32_10_n<PG>(c0, c1, c2, c3, A.seed_lo, A.seed_hi);
-            uint32_t ba[2 * PG], bb[2 * PG];
-            float z0[2 * PG], z1[2 * PG];
-#pragma unroll
-            for (int i = 0; i < PG; ++i) {
-                ba[2 * i] = c0[i];
-                bb[2 * i] = c1[i];
-                ba[2 * i + 1] = c2[i];
-                bb[2 * i + 1] = c3[i];
-            }
-            box_muller_f32_n<2 * PG>(ba, bb, z0, z1);
-#pragma unroll
-            for (int i = 0; i < 2 * PG; ++i) {
-                z[2 * i] = z0[i];
-                z[2 * i + 1] = z1[i];
-            }
-#endif
-            static_for<4 * PG>([&](auto II) {
+            static_for<4 * CN>([&](auto II) {
                 constexpr int i = decltype(II)::value;
-                constexpr int nloc = 4 * g * PG + i;
+                constexpr int nloc = 4 * C0 + i;
                 constexpr int tt = nloc / UD, d = nloc % UD;
                 // libstdc++ normal_distribution: ret * stddev + mean (dd:96-97), then clamp (dd:98-99)
                 double v = (double)z[i] * A.sigma + nomv[i];
@@ -344,7 +372,19 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
 #endif
                 }
             });
-        });
+        };
+        using std::integral_constant;
+        if constexpr (NCALL == 4) {
+            group(integral_constant<int, 0>{}, integral_constant<int, 4>{}, false);
+        } else if constexpr (NCALL == 6) {
+            group(integral_constant<int, 0>{}, integral_constant<int, 3>{}, false);
+            group(integral_constant<int, 3>{}, integral_constant<int, 3>{}, false);
+        } else {
+            static_assert(NCALL == 10 && kPcAheadCalls == 4, "full body: 4 + 3 + 3 Philox calls");
+            group(integral_constant<int, 0>{}, integral_constant<int, 4>{}, ahead != nullptr);
+            group(integral_constant<int, 4>{}, integral_constant<int, 3>{}, false);
+            group(integral_constant<int, 7>{}, integral_constant<int, 3>{}, false);
+        }
     } else {
 #pragma unroll
         for (int tt = 0; tt < kTU; ++tt)
@@ -559,8 +599,8 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
     // over their hull [lo, hi].  The comparison is widened by 1e-9 relative (the loop's own rounding is ~1e-15), and
     // anything unordered (NaN / infinite positions) keeps the point.  On the launch workloads 58-72 % of the iterations
     // remain (diff drive), 38-49 % (full body).  Measured (same box, kernel us): diff drive 50.7 -> 46.7; steering
-    // 60.4 -> 63.1 and full body 402 -> 401, where the producer, not this loop, is the workgroup's critical chain and the
-    // ~200 extra instructions only add contention -- so it is compiled in for diff drive only.
+    // 60.4 -> 63.1 and full body 402 -> 401 (357 -> 357 with pc_noise_ahead), where the producer, not this loop, is the
+    // workgroup's critical chain and the ~200 extra instructions only add contention -- compiled in for diff drive only.
     // The test costs ~600 cycles per block; the samples of a wave fan out with time, so once a block keeps more than 3/4 of
     // the window the later ones will too and the wave stops testing (*prune_on = 0) for the rest of the launch.
     int jb = 0, je = H4;
@@ -757,6 +797,8 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
     }
     const int nblocks = (H + kTU - 1) / kTU;
     const int nstates = FB ? H - 2 : H;   // states that reach the path cost (dd:199 / fb:409)
+    int prune_on = 1;
+    constexpr bool AHEAD = FB && MODE == MODE_FUSED;   // pc_noise_ahead
     __syncthreads();
 #if defined(CCV_STAMP)
     PcStamps ST;
@@ -808,7 +850,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
 #if defined(CCV_STAMP)
                                                                               , ST
 #endif
-                                                                              );
+                                                                              , (AHEAD && s >= 1) ? sh.ahead[wv] : nullptr);
             if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, s, lane, k, kk, live, kg);
             double(*st)[kPcSamples] = sh.st;
             st[0][lane] = S.x;
@@ -843,20 +885,25 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
 #else
                 const int nv = min(kTU, nstates - b * kTU);
 #endif
-                if (nv == kTU) pc_consume<kTU, MODEL>(A, sh, cost, b, lane);
+                if (nv == kTU) pc_consume<kTU, MODEL>(A, sh, cost, b, lane, 0, &prune_on);
                 else if (nv > 0) {
                     switch (nv) {
-                        case 7: pc_consume<7, MODEL>(A, sh, cost, b, lane); break;
-                        case 6: pc_consume<6, MODEL>(A, sh, cost, b, lane); break;
-                        case 5: pc_consume<5, MODEL>(A, sh, cost, b, lane); break;
-                        case 4: pc_consume<4, MODEL>(A, sh, cost, b, lane); break;
-                        case 3: pc_consume<3, MODEL>(A, sh, cost, b, lane); break;
-                        case 2: pc_consume<2, MODEL>(A, sh, cost, b, lane); break;
-                        default: pc_consume<1, MODEL>(A, sh, cost, b, lane); break;
+                        case 7: pc_consume<7, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 6: pc_consume<6, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 5: pc_consume<5, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 4: pc_consume<4, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 3: pc_consume<3, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        case 2: pc_consume<2, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
+                        default: pc_consume<1, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
                     }
                 }
                 CCV_STAMP_AT(ST, 5);
             }
+        }
+        if constexpr (AHEAD) {
+            // the wave that is not producing now produces block s+1 next: part of that block's normals, made in its idle time
+            if (((s + 1) & 1) == wv && s + 1 < nblocks && (s + 1) * kTU + kTU <= H - 1)
+                pc_noise_ahead<MODEL>(A, sh.ahead[wv], s + 1, lane, kg);
         }
         pc_barrier_lds();
         CCV_STAMP_AT(ST, 6);
