@@ -438,20 +438,28 @@ struct FinalizeArgs {
 // One wave per row n: lanes read the chunk partials of the row (fixed order => bitwise reproducible), wave-reduce them,
 // and re-derive S = sum w the same way, so no cross-block hand-off is needed.  u*[n] = V_n / S
 // (== sum_i (w_i/S) u_i of dd:222,234 up to rounding; S == 0 gives NaN exactly as dd:222 does).
-__device__ __forceinline__ double lane_partial_sum(const double* row, int n, int lane) {
-    // up to 1024 partials per pass: all 16 loads of a lane are issued before the first add (one memory latency, not 16)
-    double acc = 0.0;
+// sums of two rows of n partials each (lane l takes columns l, l+64, ...): up to 1024 columns per pass, all 32 loads of a
+// lane issued before the first add (one memory latency for both rows, not one per row)
+__device__ __forceinline__ void lane_partial_sum2(const double* row_a, const double* row_b, int n, int lane, double& sum_a,
+                                                  double& sum_b) {
+    double acc_a = 0.0, acc_b = 0.0;
     for (int c0 = 0; c0 < n; c0 += 1024) {
-        double v[16];
+        double va[16], vb[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int c = c0 + lane + 64 * i;
-            v[i] = c < n ? row[c] : 0.0;
+            const int c = min(c0 + lane + 64 * i, n - 1);   // (clamped: the loads carry no branch)
+            va[i] = row_a[c];
+            vb[i] = row_b[c];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc += v[i];
+        for (int i = 0; i < 16; ++i) {
+            const bool in = c0 + lane + 64 * i < n;
+            acc_a += in ? va[i] : 0.0;
+            acc_b += in ? vb[i] : 0.0;
+        }
     }
-    return acc;
+    sum_a = acc_a;
+    sum_b = acc_b;
 }
 
 __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
@@ -461,8 +469,8 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
     const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int nrow = n < A.R ? n : A.R;
     // S = sum w and this wave's row are fetched together
-    double s = lane_partial_sum(A.partial + (size_t)A.R * A.nchunks, A.nchunks, lane);
-    double v = lane_partial_sum(A.partial + (size_t)nrow * A.nchunks, A.nchunks, lane);
+    double s, v;
+    lane_partial_sum2(A.partial + (size_t)A.R * A.nchunks, A.partial + (size_t)nrow * A.nchunks, A.nchunks, lane, s, v);
     s = wave_sum(s);
     v = wave_sum(v);
     if (n < A.R && lane == 0) {
@@ -475,17 +483,17 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
             double a[16], b[16], z[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {   // all loads first: one memory latency per 1024 partials
-                const int c = c0 + lane + 64 * i;
-                const bool in = c < A.nchunks;
-                a[i] = in ? A.statpart[c * 3 + 0] : INFINITY;
-                b[i] = in ? A.statpart[c * 3 + 1] : -INFINITY;
-                z[i] = in ? A.statpart[c * 3 + 2] : 0.0;
+                const int c = min(c0 + lane + 64 * i, A.nchunks - 1);
+                a[i] = A.statpart[c * 3 + 0];
+                b[i] = A.statpart[c * 3 + 1];
+                z[i] = A.statpart[c * 3 + 2];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                mn = fmin(mn, a[i]);
-                mx = fmax(mx, b[i]);
-                nz += z[i];
+                const bool in = c0 + lane + 64 * i < A.nchunks;
+                mn = fmin(mn, in ? a[i] : INFINITY);
+                mx = fmax(mx, in ? b[i] : -INFINITY);
+                nz += in ? z[i] : 0.0;
             }
         }
         mn = wave_min(mn);
