@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--workload", default="C2", help="C2 (headline) | C3 | C4")
     ap.add_argument("--samples-per-gpu", type=int, default=None)
     ap.add_argument("--path", default=None, help="reference path instead of the workload's: straight | sinusoid | dkan")
+    ap.add_argument("--closed-loop", action="store_true",
+                    help="not the headline: the device-resident closed loop (pose advanced by u*[0] and the window rebuilt "
+                         "on the device every step; the workload's path generator with the course extended so that it never ends)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-state-store", action="store_true", help="skip the KxH x,y buffer (not the headline)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel hipEvents in the timed region")
@@ -154,7 +157,22 @@ def main():
     # N > 1: per-GPU partials [sum w, sum w*u] -> one small RCCL all-reduce over xGMI -> every rank divides (no host sync)
     driver = sharded.ShardedMPPI(sharded.DevicePartials(ctl)) if world > 1 else None
 
+    if args.closed_loop:
+        if world > 1:
+            print("bench.py: --closed-loop is a single-GPU measurement", file=sys.stderr)
+            sys.exit(2)
+        # the course must outlast warm-up + timed steps at the largest speed the controller may command
+        need = (args.warmup + args.steps + 8) * max(abs(p.u_max[0]), abs(p.u_min[0])) * p.dt + 2.0 * p.horizon * p.v_ref * p.dt
+        cl_px, cl_py = amd.make_path(w.path, p.resolution, length=max(need, 10.0))
+        cl_start = np.zeros(p.nstate)
+        cl_start[0], cl_start[1] = cl_px[0], cl_py[0]
+        ctl.resident_set_path(cl_px, cl_py)
+        ctl.resident_set_pose(cl_start)
+
     def step(i):
+        if args.closed_loop:
+            ctl.resident_step_enqueue(p.dt, seed, i, advance=True)
+            return
         s, xr, yr, yaw0 = inputs[i % len(inputs)]
         if world == 1:
             ctl.iterate_enqueue(s, p.dt, xr, yr, yaw0, seed, i)
@@ -178,6 +196,9 @@ def main():
         if world > 1:
             fence()
     fence()
+    if args.closed_loop:   # back to the start of the course (the set-up iterations above moved the robot)
+        ctl.resident_set_pose(cl_start)
+        ctl.set_nominal(np.zeros((p.horizon - 1, p.udim)))
     for i in range(args.warmup):
         step(i)
     fence()
@@ -221,7 +242,9 @@ def main():
             "config": {"workload": "%s: %s, u_dim=%d, launch parameters" % (w.name, w.description.replace(
                 "K=%d" % p.num_samples, "K=%d" % k_total), p.udim),
                        "samples_per_gpu": k_local, "horizon": p.horizon, "sharding": "K over %d GPU(s)" % world,
-                       "state_store": not args.no_state_store},
+                       "state_store": not args.no_state_store,
+                       **({"closed_loop": "device-resident: plant + get_CurrentIndex + calc_RefPath on the device, "
+                                          "%d path poses" % len(cl_px)} if args.closed_loop else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "k_rollout_pc" if p.model == "full_body" else "k_rollout_r3",
@@ -232,6 +255,11 @@ def main():
                          "iteration_achieved": (B * k_local / iter_avg_s / 1e9) if iter_avg_s > 0 else None,
                          "iteration_frac": (B * k_local / iter_avg_s / 1e9 / HBM_PEAK_GBS) if iter_avg_s > 0 else None},
         }
+        if args.closed_loop:
+            tr = ctl.resident_read_trace()
+            d = np.hypot(cl_px[None, :] - tr[:, 0:1], cl_py[None, :] - tr[:, 1:2]).min(axis=1)
+            out["closed_loop"] = {"ticks": int(len(tr)), "distance_travelled_m": float(np.hypot(np.diff(tr[:, 0]), np.diff(tr[:, 1])).sum()),
+                                  "path_error_rms_m": float(np.sqrt(np.mean(d * d))), "path_error_max_m": float(d.max())}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

@@ -177,6 +177,41 @@ class MPPIController:
     def apply_partials_enqueue(self, dev_ptr):
         self._check(self.lib.ccv_mppi_apply_partials_enqueue(self._h, C.c_void_p(dev_ptr)))
 
+    # ---- device-resident closed loop (get_CurrentIndex + calc_RefPath + plant on the device) ----
+    def resident_set_path(self, path_x, path_y, resolution=None):
+        px, py = capi.as_f64(path_x), capi.as_f64(path_y)
+        res = self.params.resolution if resolution is None else resolution
+        self._check(self.lib.ccv_mppi_resident_set_path(self._h, capi.dptr(px), capi.dptr(py), len(px), float(res)))
+
+    def resident_set_pose(self, state):
+        x = self._x0(state)
+        self._check(self.lib.ccv_mppi_resident_set_pose(self._h, capi.dptr(x)))
+
+    def resident_step_enqueue(self, dt, seed, iteration, advance=True):
+        """One tick, no host data: (advance) pose += plant(u*[0]) -> window from the pose -> MPPI iteration."""
+        self._check(self.lib.ccv_mppi_resident_step_enqueue(self._h, float(dt), int(seed), int(iteration),
+                                                            1 if advance else 0))
+
+    def resident_step_partials_enqueue(self, dt, seed, iteration, advance, dev_ptr):
+        self._check(self.lib.ccv_mppi_resident_step_partials_enqueue(self._h, float(dt), int(seed), int(iteration),
+                                                                     1 if advance else 0, C.c_void_p(dev_ptr)))
+
+    def resident_read(self):
+        """(state, current_index, x_ref, y_ref, yaw_ref0, steps) of the last tick; synchronises."""
+        st = np.zeros(5)
+        xr, yr = np.zeros(self.H), np.zeros(self.H)
+        idx, yaw0, steps = C.c_int32(), C.c_double(), C.c_int64()
+        self._check(self.lib.ccv_mppi_resident_read(self._h, capi.dptr(st), C.byref(idx), capi.dptr(xr), capi.dptr(yr),
+                                                    C.byref(yaw0), C.byref(steps)))
+        return st[:self.params.nstate].copy(), idx.value, xr, yr, yaw0.value, steps.value
+
+    def resident_read_trace(self, max_rows=8192):
+        """Poses of the last ticks, oldest first: rows (x, y, yaw, roll, pitch, current_index)."""
+        rows = np.zeros((max_rows, 6))
+        n = C.c_int32()
+        self._check(self.lib.ccv_mppi_resident_read_trace(self._h, int(max_rows), capi.dptr(rows), C.byref(n)))
+        return rows[:n.value].copy()
+
     # ---- measurement ----
     def timing_enable(self, on=True, every=1):
         self._check(self.lib.ccv_mppi_timing_enable(self._h, (max(1, int(every)) if on else 0)))
@@ -201,22 +236,24 @@ def calc_ref_path(path_x, path_y, cur_x, cur_y, v_ref, dt, resolution, horizon):
     return idx, xr, yr, yaw
 
 
-def make_path(kind, resolution=0.1):
-    """The synthetic reference paths of the BASELINE configs."""
+def make_path(kind, resolution=0.1, length=None):
+    """The synthetic reference paths of the BASELINE configs.  `length` overrides the course length of the
+    cosine generator (launch value 10 m) for closed loops that must not run out of path."""
     lib = capi.load()
-    cap = 4096
+    cap = 4096 if length is None else int(length / resolution) + 16
     px, py = np.zeros(cap), np.zeros(cap)
     if kind == "dkan":   # dkan_path_creator.cpp
         n = lib.ccv_mppi_path_dkan(resolution, capi.dptr(px), capi.dptr(py), cap)
     else:
         if kind == "straight":   # creator defaults A=0, delta=1.57, length 10 (reference_path_creator.cpp:6-19)
-            A, om, de, length = (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.57, 1.57, 1.57), 10.0
+            A, om, de, course = (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.57, 1.57, 1.57), 10.0
         elif kind == "sinusoid":   # launch/diff_drive_mppi.launch:15-26
-            A, om, de, length = (1.0, 0.0, 0.0), (0.25, 0.0, 0.0), (0.0, 0.0, 0.0), 10.0
+            A, om, de, course = (1.0, 0.0, 0.0), (0.25, 0.0, 0.0), (0.0, 0.0, 0.0), 10.0
         else:
             raise KeyError(kind)
         A, om, de = capi.as_f64(A), capi.as_f64(om), capi.as_f64(de)
-        n = lib.ccv_mppi_path_cosine(capi.dptr(A), capi.dptr(om), capi.dptr(de), resolution, length, 0.0, 0.0,
+        n = lib.ccv_mppi_path_cosine(capi.dptr(A), capi.dptr(om), capi.dptr(de), resolution,
+                                     course if length is None else float(length), 0.0, 0.0,
                                      capi.dptr(px), capi.dptr(py), cap)
     if n < 0:
         raise MPPIError(n, "path generator")

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <new>
 #include <string>
@@ -14,6 +15,7 @@
 #include "mppi_kernels.h"
 #include "mppi_rollout_pc.h"
 #include "mppi_rollout_r3.h"
+#include "mppi_resident.h"
 
 using namespace ccv;
 
@@ -37,6 +39,16 @@ struct ccv_mppi_handle {
     double* d_stats = nullptr;
     double* d_cmin = nullptr;
     unsigned long long* d_dbg = nullptr;   // CCV_STAMP diagnostic builds
+    // device-resident closed loop (mppi_resident.h)
+    ResidentFrame* d_frame = nullptr;
+    double* d_path = nullptr;    // [2][n_path]: x then y
+    double* d_trace = nullptr;   // [kTraceRows][6]
+    static constexpr int kTraceRows = 8192;
+    int n_path = 0;
+    double path_resolution = 0.0;
+    bool have_pose = false;
+    int64_t res_steps = 0;                 // k_advance launches since the pose was set
+    double res_angle_abs[3] = {0, 0, 0};   // conservative bounds on |yaw|, |roll|, |pitch| of the resident pose (fast_trig_safe)
     // queue-depth throttle for the asynchronous entry points: beyond a few dozen iterations in flight the HIP runtime's
     // enqueue path slows down several-fold (measured: 12 us/call at depth <= 64, 90 us/call at depth 512), so every
     // kThrottleEvery-th enqueue records an event and waits for the one recorded kThrottleSlots marks earlier
@@ -360,12 +372,21 @@ int check_iter_args(ccv_mppi_handle* h, const double* x0, double dt, const doubl
 }
 
 // the fused iteration: sample+rollout+cost kernel, then the weighted update
+// (resident: the pose and the window are taken from h->d_frame on the device; x0 then carries only the bounds on the pose
+//  angles that fast_trig_safe() needs, and x_ref / y_ref are not read)
 int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref, const double* y_ref,
-                      double yaw_ref0, uint64_t seed, uint64_t iter, bool normalise, double* vec_out) {
+                      double yaw_ref0, uint64_t seed, uint64_t iter, bool normalise, double* vec_out, bool resident = false) {
     RolloutArgs A;
     Window W;
     fill_args(h, A, x0, dt, yaw_ref0, seed, iter);
-    fill_window(h, W, x0, x_ref, y_ref);
+    if (resident) {
+        std::memset(&W, 0, sizeof(W));
+        A.frame = h->d_frame;
+        if (!h->coop || !fast_trig_safe(h, A, MODE_FUSED))
+            return fail(h, CCV_MPPI_ERR_STATE, "the resident loop needs the cooperative kernels and bounded pose angles");
+    } else {
+        fill_window(h, W, x0, x_ref, y_ref);
+    }
     A.store_u = 1;
     A.store_xy = (h->cfg.flags & CCV_MPPI_FLAG_NO_STATE_STORE) ? 0 : 1;
     A.do_cost = 1;
@@ -626,6 +647,134 @@ int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partia
     int rc = flush_pending(h);
     if (rc) return rc;
     h->pending_vec = dev_partials;
+    return CCV_MPPI_OK;
+}
+
+// ---- device-resident closed loop (mppi_resident.h) ------------------------------------------------------------------
+
+int ccv_mppi_resident_set_path(ccv_mppi_handle* h, const double* path_x, const double* path_y, int32_t n_path,
+                               double resolution) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!path_x || !path_y || n_path < 1 || !(resolution > 0.0)) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "path: null, empty or resolution <= 0");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // (a queued k_advance may still read the old path)
+    if (h->d_path) HIP_TRY(h, hipFree(h->d_path));
+    h->d_path = nullptr;
+    h->n_path = 0;
+    HIP_TRY(h, hipMalloc(&h->d_path, (size_t)2 * n_path * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(h->d_path, path_x, (size_t)n_path * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_path + n_path, path_y, (size_t)n_path * sizeof(double), hipMemcpyHostToDevice));
+    if (!h->d_frame) {
+        HIP_TRY(h, hipMalloc(&h->d_frame, sizeof(ResidentFrame)));
+        HIP_TRY(h, hipMemset(h->d_frame, 0, sizeof(ResidentFrame)));
+        HIP_TRY(h, hipMalloc(&h->d_trace, (size_t)ccv_mppi_handle::kTraceRows * 6 * sizeof(double)));
+        HIP_TRY(h, hipMemset(h->d_trace, 0, (size_t)ccv_mppi_handle::kTraceRows * 6 * sizeof(double)));
+    }
+    h->n_path = n_path;
+    h->path_resolution = resolution;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_resident_set_pose(ccv_mppi_handle* h, const double* state) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!state) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "state is null");
+    if (!h->d_frame) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_resident_set_path first");
+    const int nx = h->cfg.model == CCV_MPPI_FULL_BODY ? 5 : 3;
+    // pose and step counter: the head of the frame
+    struct { double x0[5]; double yaw_ref0; int32_t index, steps; } head{};
+    for (int i = 0; i < nx; ++i) head.x0[i] = state[i];
+    static_assert(offsetof(ResidentFrame, W) == sizeof(head), "frame head layout");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(h->d_frame, &head, sizeof(head), hipMemcpyHostToDevice));
+    for (int i = 0; i < 3; ++i) h->res_angle_abs[i] = std::fabs(head.x0[2 + i]);
+    h->res_steps = 0;
+    h->have_pose = true;
+    return CCV_MPPI_OK;
+}
+
+namespace {
+int resident_step(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance, bool normalise, double* vec_out) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!(dt == dt)) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "dt is NaN");
+    if (!h->d_frame || !h->have_pose) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_resident_set_path and _set_pose first");
+    if (advance) {
+        if (int rc = flush_pending(h)) return rc;   // the command is u*[0]: a deferred division has to happen now
+        // u* is a weighted mean of clamped samples (or what ccv_mppi_set_nominal put there): bound the angles it can reach
+        const ccv_mppi_config& c = h->cfg;
+        auto lim = [&](int d) { return std::fmax(std::fmax(std::fabs(c.u_min[d]), std::fabs(c.u_max[d])), h->inj_absmax[d]); };
+        h->res_angle_abs[0] += lim(1) * std::fabs(dt);
+        if (c.model == CCV_MPPI_FULL_BODY) {
+            h->res_angle_abs[1] += lim(3) * std::fabs(dt);
+            h->res_angle_abs[2] += lim(4) * std::fabs(dt);
+        }
+    }
+    AdvanceArgs V;
+    V.frame = h->d_frame;
+    V.path_x = h->d_path;
+    V.path_y = h->d_path + h->n_path;
+    V.nominal = h->d_nominal;
+    V.trace = h->d_trace;
+    V.dt = dt;
+    V.v_ref = h->cfg.v_ref;
+    V.resolution = h->path_resolution;
+    V.n_path = h->n_path;
+    V.H = h->H;
+    V.model = h->cfg.model;
+    V.advance = advance ? 1 : 0;
+    V.trace_cap = ccv_mppi_handle::kTraceRows;
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(kAdvanceThreads), 0, h->stream, V);
+    HIP_TRY(h, hipGetLastError());
+    h->res_steps += 1;
+    const double bounds[5] = {0.0, 0.0, h->res_angle_abs[0], h->res_angle_abs[1], h->res_angle_abs[2]};
+    return enqueue_iteration(h, bounds, dt, nullptr, nullptr, 0.0, seed, iter, normalise, vec_out, true);
+}
+}  // namespace
+
+int ccv_mppi_resident_step_enqueue(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance) {
+    return resident_step(h, dt, seed, iter, advance, true, nullptr);
+}
+
+int ccv_mppi_resident_step_partials_enqueue(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance,
+                                            double* dev_partials) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!dev_partials) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "dev_partials is null");
+    if (h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT)
+        return fail(h, CCV_MPPI_ERR_INVALID_ARG, "MIN_SHIFT needs a cross-device min; not supported with partials");
+    return resident_step(h, dt, seed, iter, advance, false, dev_partials);
+}
+
+int ccv_mppi_resident_read(ccv_mppi_handle* h, double* state, int32_t* current_index, double* x_ref, double* y_ref,
+                           double* yaw_ref0, int64_t* steps) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!h->d_frame || !h->have_pose) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_resident_set_path and _set_pose first");
+    ResidentFrame F;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(&F, h->d_frame, sizeof(F), hipMemcpyDeviceToHost));
+    const int nx = h->cfg.model == CCV_MPPI_FULL_BODY ? 5 : 3;
+    if (state) for (int i = 0; i < nx; ++i) state[i] = F.x0[i];
+    if (current_index) *current_index = F.index;
+    if (x_ref) for (int i = 0; i < h->H; ++i) x_ref[i] = F.x_ref[i];
+    if (y_ref) for (int i = 0; i < h->H; ++i) y_ref[i] = F.y_ref[i];
+    if (yaw_ref0) *yaw_ref0 = F.yaw_ref0;
+    if (steps) *steps = F.steps;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_resident_read_trace(ccv_mppi_handle* h, int32_t max_rows, double* rows, int32_t* n_rows) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!rows || !n_rows || max_rows < 0) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "rows / n_rows null or max_rows < 0");
+    if (!h->d_frame || !h->have_pose) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_resident_set_path and _set_pose first");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // the last min(steps, capacity, max_rows) launches, oldest first
+    const int64_t cap = ccv_mppi_handle::kTraceRows;
+    const int64_t have = h->res_steps < cap ? h->res_steps : cap;
+    const int64_t n = have < max_rows ? have : max_rows;
+    std::vector<double> ring((size_t)cap * 6);
+    HIP_TRY(h, hipMemcpy(ring.data(), h->d_trace, ring.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t step = h->res_steps - n + i;
+        std::memcpy(rows + i * 6, ring.data() + (step % cap) * 6, 6 * sizeof(double));
+    }
+    *n_rows = (int32_t)n;
     return CCV_MPPI_OK;
 }
 

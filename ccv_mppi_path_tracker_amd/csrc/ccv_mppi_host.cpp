@@ -23,6 +23,36 @@ int nearest_index(const double* px, const double* py, int n, double x, double y)
     return best;
 }
 
+// sin and cos as the device computes them (csrc/fast_trig.h fast_sincos, restated operation by operation: three-step
+// Cody-Waite reduction by pi/2, fdlibm kernel polynomials, quadrant selection), so that a pose advanced here and one
+// advanced by k_advance on the device are the same bits.  |x| <= 1e5 as on the device; at most 1 ulp from libm.
+void spec_sincos(double x, double& s, double& c) {
+    const double fn = std::rint(x * 6.36619772367581382433e-01);
+    double r = std::fma(-fn, 1.57079632673412561417e+00, x);
+    r = std::fma(-fn, 6.07710050630396597660e-11, r);
+    r = std::fma(-fn, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    double ps = std::fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = std::fma(z, ps, 2.75573137070700676789e-06);
+    ps = std::fma(z, ps, -1.98412698298579493134e-04);
+    ps = std::fma(z, ps, 8.33333333332248946124e-03);
+    ps = std::fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = std::fma(z * r, ps, r);
+    double pc = std::fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = std::fma(z, pc, -2.75573143513906633035e-07);
+    pc = std::fma(z, pc, 2.48015872894767294178e-05);
+    pc = std::fma(z, pc, -1.38888888888741095749e-03);
+    pc = std::fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+    const int q = static_cast<int>(fn);
+    const double sa = (q & 1) ? cr : sr;
+    const double ca = (q & 1) ? sr : cr;
+    s = (q & 2) ? -sa : sa;
+    c = ((q + 1) & 2) ? -ca : ca;
+}
+
 }  // namespace
 
 extern "C" {
@@ -82,8 +112,11 @@ int ccv_mppi_path_dkan(double resolution, double* path_x, double* path_y, int32_
 int ccv_mppi_plant_step(int32_t model, double* state, const double* u, double dt) {
     if (!state || !u || model < CCV_MPPI_DIFF_DRIVE || model > CCV_MPPI_FULL_BODY) return CCV_MPPI_ERR_INVALID_ARG;
     const double heading = model == CCV_MPPI_DIFF_DRIVE ? state[2] : state[2] + u[2];
-    state[0] = state[0] + u[0] * std::cos(heading) * dt;
-    state[1] = state[1] + u[0] * std::sin(heading) * dt;
+    if (!(std::fabs(heading) <= 1.0e5)) return CCV_MPPI_ERR_INVALID_ARG;   // (the range spec_sincos is specified for)
+    double sn, cs;
+    spec_sincos(heading, sn, cs);
+    state[0] = state[0] + u[0] * cs * dt;
+    state[1] = state[1] + u[0] * sn * dt;
     state[2] = state[2] + u[1] * dt;
     if (model == CCV_MPPI_FULL_BODY) {
         state[3] = state[3] + u[3] * dt;

@@ -43,6 +43,18 @@ struct Window {
     double c[kMaxH];
 };
 
+// Device-resident closed loop (k_advance below): the pose, the window built from it and its distance coefficients stay
+// in HBM; a rollout launched with RolloutArgs::frame set takes x0, yaw_ref0 and the window from here instead of from its
+// kernel arguments.
+struct ResidentFrame {
+    double x0[5];      // x, y, yaw[, roll, pitch]
+    double yaw_ref0;   // yaw_ref[0] of calc_RefPath() (fb:408 is its only reader)
+    int32_t index;     // current_index_ (get_CurrentIndex())
+    int32_t steps;     // k_advance launches so far
+    Window W;
+    double x_ref[kMaxH], y_ref[kMaxH];
+};
+
 struct RolloutArgs {
     double x0[5];
     double dt;
@@ -69,8 +81,38 @@ struct RolloutArgs {
     const double* pending_vec;
     double* nominal_w;
     double* stats_w;
+    const ResidentFrame* frame;   // device-resident pose and window (null: x0, yaw_ref0 and the Window argument)
     unsigned long long* dbg;   // diagnostic builds only (CCV_STAMP): per-phase cycle sums
 };
+
+// the kernel arguments with the resident pose substituted (wave-uniform scalar loads)
+__device__ __forceinline__ RolloutArgs with_resident_pose(const RolloutArgs& Ak) {
+    RolloutArgs A = Ak;
+    if (Ak.frame) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) A.x0[i] = Ak.frame->x0[i];
+        A.yaw_ref0 = Ak.frame->yaw_ref0;
+    }
+    return A;
+}
+
+// window coefficients -> LDS, padded to a multiple of 4 points with c = +inf (never the minimum)
+template <class SH>
+__device__ __forceinline__ void stage_window(const RolloutArgs& A, const Window& Wk, SH& sh, int nthreads) {
+    const int H = A.H, H4 = (H + 3) & ~3;
+    if (A.frame) {
+        const Window& W = A.frame->W;
+        for (int j = threadIdx.x; j < H4; j += nthreads) {
+            sh.ab[j] = j < H ? make_double2(W.a[j], W.b[j]) : make_double2(0.0, 0.0);
+            sh.c[j] = j < H ? W.c[j] : INFINITY;
+        }
+    } else {
+        for (int j = threadIdx.x; j < H4; j += nthreads) {
+            sh.ab[j] = j < H ? make_double2(Wk.a[j], Wk.b[j]) : make_double2(0.0, 0.0);
+            sh.c[j] = j < H ? Wk.c[j] : INFINITY;
+        }
+    }
+}
 
 template <int N, class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {

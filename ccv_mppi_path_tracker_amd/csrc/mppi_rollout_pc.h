@@ -772,20 +772,15 @@ __device__ __forceinline__ void pc_partial_update(const RolloutArgs& A, PcShared
 }
 
 template <int MODEL, int MODE>
-__global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutArgs A, const Window W) {
+__global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutArgs Ak, const Window Wk) {
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     constexpr bool COST = MODE != MODE_ROLLOUT;
     __shared__ PcShared<MODEL> sh;
+    const RolloutArgs A = with_resident_pose(Ak);
     const int H = A.H;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if constexpr (COST) {
-        const int H4 = (H + 3) & ~3;
-        for (int j = threadIdx.x; j < H4; j += kPcWaves * 64) {
-            sh.ab[j] = j < H ? make_double2(W.a[j], W.b[j]) : make_double2(0.0, 0.0);
-            sh.c[j] = j < H ? W.c[j] : INFINITY;
-        }
-    }
+    if constexpr (COST) stage_window(A, Wk, sh, kPcWaves * 64);
     if constexpr (MODE == MODE_FUSED) pc_stage_nominal<MODEL>(A, sh, kPcWaves * 64);
     const int k = blockIdx.x * kPcSamples + lane;
     const bool live = k < A.K;

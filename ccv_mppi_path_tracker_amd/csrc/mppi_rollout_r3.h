@@ -58,21 +58,16 @@ __device__ __forceinline__ void r3_update_fetch0(const RolloutArgs& A, double (&
 }
 
 template <int MODEL, int MODE>
-__global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutArgs A, const Window W) {
+__global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutArgs Ak, const Window Wk) {
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     constexpr bool COST = MODE != MODE_ROLLOUT;
     __shared__ R3Shared<MODEL> sh;
     static_assert(sizeof(sh.p) + sizeof(sh.ab) + sizeof(sh.c) >= kR3Waves * kR3RB * (kPcSamples + 1) * sizeof(double), "epilogue buffers");
+    const RolloutArgs A = with_resident_pose(Ak);
     const int H = A.H;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if constexpr (COST) {
-        const int H4 = (H + 3) & ~3;
-        for (int j = threadIdx.x; j < H4; j += kR3Waves * 64) {
-            sh.ab[j] = j < H ? make_double2(W.a[j], W.b[j]) : make_double2(0.0, 0.0);
-            sh.c[j] = j < H ? W.c[j] : INFINITY;
-        }
-    }
+    if constexpr (COST) stage_window(A, Wk, sh, kR3Waves * 64);
     if constexpr (MODE == MODE_FUSED) pc_stage_nominal<MODEL>(A, sh, kR3Waves * 64);
     const int k = blockIdx.x * kPcSamples + lane;
     const bool live = k < A.K;

@@ -155,6 +155,32 @@ int ccv_mppi_iterate_partials_enqueue(ccv_mppi_handle* h, const double* x0, doub
  * unchanged until then, or until ccv_mppi_synchronize / ccv_mppi_get_nominal, which perform it at once. */
 int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partials);
 
+/* ---- device-resident closed loop -------------------------------------------------- */
+/* The per-tick prologue of run() on the device: the whole reference path and the pose live in HBM, and every step does
+ *   (advance != 0) pose <- pose advanced for dt by the command u*[0] of the previous step (the Euler model of
+ *                  predict_NextState(), dd:103-110 / sd:119-126 / fb:445-463: the closed-loop plant, what the robot does
+ *                  between two ticks; ccv_mppi_plant_step() in ccv_mppi_host.h is the same arithmetic on the host)
+ *   get_CurrentIndex() (dd:126-140) + calc_RefPath() (dd:156-181) from that pose, then the iteration itself
+ * with no host data in between: a closed loop costs three kernel launches per tick and no PCIe traffic.  Window, index
+ * and pose are bit-identical to ccv_mppi_calc_ref_path() / ccv_mppi_plant_step() on the host; yaw_ref[0] (read by fb:408
+ * only) comes from the device atan2 and may differ from libm's in the last place.  v_ref and the horizon are the
+ * handle's; `resolution` is the spacing of the path poses (resolution_, dd:160).  Needs the default (cooperative)
+ * kernels. */
+int ccv_mppi_resident_set_path(ccv_mppi_handle* h, const double* path_x, const double* path_y, int32_t n_path,
+                               double resolution);
+/* state: (x, y, yaw[, roll, pitch]); also restarts the step counter and the trace */
+int ccv_mppi_resident_set_pose(ccv_mppi_handle* h, const double* state);
+int ccv_mppi_resident_step_enqueue(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance);
+/* K sharded over devices: as ccv_mppi_iterate_partials_enqueue; every device advances the same pose with the same u* */
+int ccv_mppi_resident_step_partials_enqueue(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance,
+                                            double* dev_partials);
+/* Synchronises; any output pointer may be NULL.  x_ref / y_ref: H values, the window of the last step. */
+int ccv_mppi_resident_read(ccv_mppi_handle* h, double* state, int32_t* current_index, double* x_ref, double* y_ref,
+                           double* yaw_ref0, int64_t* steps);
+/* The poses of the last steps, oldest first: rows of (x, y, yaw, roll, pitch, current_index); at most max_rows and at
+ * most the 8192 most recent.  This is what record_state.py:118-139 logs from tf. */
+int ccv_mppi_resident_read_trace(ccv_mppi_handle* h, int32_t max_rows, double* rows, int32_t* n_rows);
+
 /* ---- measurement ----------------------------------------------------------------------------------- */
 /* on = 1: every iteration records hipEvents around the dominant kernel and the whole launch sequence; on = n > 1: every
  * n-th iteration only (keeps the event overhead out of a throughput measurement); 0: off.

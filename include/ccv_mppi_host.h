@@ -35,7 +35,9 @@ int ccv_mppi_path_cosine(const double* A, const double* omega, const double* del
 /* (0,0) -> (17.7,0) -> (17.7,8) -> (0,8) sampled every `resolution` metres. Returns the number of poses written. */
 int ccv_mppi_path_dkan(double resolution, double* path_x, double* path_y, int32_t cap);
 
-/* state (x, y, yaw[, roll, pitch]) advanced one Euler step with the controls u (model's control order). */
+/* state (x, y, yaw[, roll, pitch]) advanced one Euler step with the controls u (model's control order).  sin / cos of
+ * the heading are the specified polynomial evaluation the device uses (<= 1 ulp from libm), so that this and the resident
+ * loop's plant (ccv_mppi_resident_step_enqueue, ccv_mppi.h) give the same bits; |heading| <= 1e5. */
 int ccv_mppi_plant_step(int32_t model, double* state, const double* u, double dt);
 
 #ifdef __cplusplus

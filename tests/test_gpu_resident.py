@@ -1,0 +1,167 @@
+"""GPU tests (-m gpu) of the device-resident closed loop (include/ccv_mppi.h, "device-resident closed loop"):
+get_CurrentIndex() + calc_RefPath() (dd:126-181) and the closed-loop plant on the device.
+
+Checker: the host prologue (ccv_mppi_calc_ref_path / ccv_mppi_plant_step, themselves checked against the oracle in
+tests/test_host_prologue.py) driving the ordinary ccv_mppi_iterate path.  Everything integer or copied (index, x_ref,
+y_ref) and everything computed with specified arithmetic (pose, window coefficients -> u*) must be bit-identical;
+yaw_ref[0] comes from the device atan2 and is compared to 4 ulp (it only enters the full-body yaw cost, fb:408).
+"""
+import numpy as np
+import pytest
+
+import helpers
+import ccv_mppi_path_tracker_amd as amd
+from ccv_mppi_path_tracker_amd import capi, configs
+from ccv_mppi_path_tracker_amd.controller import MPPIController, MPPIError
+
+pytestmark = pytest.mark.gpu
+
+WORKLOADS = {"diff_drive": "C2", "steering_diff_drive": "C3", "full_body": "C4"}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(gpu_required):
+    capi.load()
+
+
+def start(p, px, py, lateral=0.05):
+    s = np.zeros(p.nstate)
+    s[0], s[1], s[2] = px[0], py[0] + lateral, 0.02
+    return s
+
+
+def host_loop(p, px, py, s0, ticks, seed, num_samples):
+    """The same closed loop with the prologue on the host: window -> iterate -> plant."""
+    g = MPPIController(p, num_samples=num_samples)
+    s = s0.copy()
+    poses, wins, us = [], [], []
+    u = None
+    for it in range(ticks):
+        if it > 0:
+            s = amd.plant_step(p.model, s, u[0], p.dt)
+        idx, xr, yr, yaw = amd.calc_ref_path(px, py, s[0], s[1], p.v_ref, p.dt, p.resolution, p.horizon)
+        u = g.iterate(s, p.dt, xr, yr, yaw[0], seed, it, want_stats=False)
+        poses.append(s.copy())
+        wins.append((idx, xr.copy(), yr.copy(), yaw[0]))
+        us.append(u.copy())
+    return poses, wins, us
+
+
+@pytest.mark.parametrize("model", ["diff_drive", "steering_diff_drive"])
+def test_resident_loop_is_the_host_loop_bit_for_bit(model):
+    w = configs.workload(WORKLOADS[model], num_samples=1024)
+    p = w.params
+    px, py = amd.make_path(w.path)
+    s0 = start(p, px, py)
+    ticks, seed = 25, 77
+    poses, wins, us = host_loop(p, px, py, s0, ticks, seed, 1024)
+    g = MPPIController(p, num_samples=1024)
+    g.resident_set_path(px, py)
+    g.resident_set_pose(s0)
+    for it in range(ticks):
+        g.resident_step_enqueue(p.dt, seed, it, advance=it > 0)
+        if it in (0, 1, 7, ticks - 1):   # (reading synchronises; the ticks in between run back to back)
+            st, idx, xr, yr, yaw0, steps = g.resident_read()
+            assert steps == it + 1
+            assert idx == wins[it][0]
+            np.testing.assert_array_equal(st, poses[it])
+            np.testing.assert_array_equal(xr, wins[it][1])
+            np.testing.assert_array_equal(yr, wins[it][2])
+            assert abs(yaw0 - wins[it][3]) <= 4 * np.spacing(abs(wins[it][3]))
+            np.testing.assert_array_equal(g.get_nominal(), us[it])
+    tr = g.resident_read_trace()
+    assert tr.shape == (ticks, 6)
+    np.testing.assert_array_equal(tr[:, :3], np.array(poses))
+    np.testing.assert_array_equal(tr[:, 5], np.array([wn[0] for wn in wins], dtype=float))
+    assert tr[-1, 0] > tr[0, 0] + 0.2   # the loop drove along the path
+
+
+def test_resident_loop_full_body_within_tolerance():
+    """fb:408 reads yaw_ref[0] (device atan2 vs libm: last-place differences), so the loop is compared to tolerance."""
+    w = configs.workload("C4", num_samples=1024)
+    p = w.params
+    px, py = amd.make_path(w.path)
+    s0 = start(p, px, py)
+    ticks, seed = 12, 5
+    poses, wins, us = host_loop(p, px, py, s0, ticks, seed, 1024)
+    g = MPPIController(p, num_samples=1024)
+    g.resident_set_path(px, py)
+    g.resident_set_pose(s0)
+    for it in range(ticks):
+        g.resident_step_enqueue(p.dt, seed, it, advance=it > 0)
+    st, idx, xr, yr, yaw0, steps = g.resident_read()
+    assert steps == ticks and idx == wins[-1][0]
+    np.testing.assert_allclose(st, poses[-1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(g.get_nominal(), us[-1], rtol=1e-7, atol=1e-9)
+
+
+def test_resident_index_gate_ties_and_path_end():
+    """get_CurrentIndex(): first of equal distances, index 0 when nothing is inside the 100 m gate; calc_RefPath():
+    the final pose repeats past the end of the path (dd:169-172)."""
+    p = configs.diff_drive_defaults(256, 30)
+    # a path that passes the same point twice (equal distances), longer than one scan stride of the kernel
+    t = np.arange(700) * 0.1
+    px = np.concatenate([t, t[::-1]])
+    py = np.zeros_like(px)
+    g = MPPIController(p)
+    g.resident_set_path(px, py, 0.1)
+    for pose in ([3.0, 0.2, 0.0], [69.9, -0.1, 0.0], [500.0, 0.0, 0.0], [-20.0, 5.0, 1.0], [35.0, 0.0, 0.0]):
+        g.resident_set_pose(pose)
+        g.resident_step_enqueue(p.dt, 1, 0, advance=False)
+        st, idx, xr, yr, yaw0, _ = g.resident_read()
+        want_idx, wxr, wyr, wyaw = amd.calc_ref_path(px, py, pose[0], pose[1], p.v_ref, p.dt, 0.1, p.horizon)
+        assert idx == want_idx
+        np.testing.assert_array_equal(xr, wxr)
+        np.testing.assert_array_equal(yr, wyr)
+        np.testing.assert_array_equal(st, pose)
+    # near the end of a short path the window runs past it
+    px2, py2 = amd.make_path("straight")
+    g.resident_set_path(px2, py2, 0.1)
+    g.resident_set_pose([px2[-3], 0.0, 0.0])
+    g.resident_step_enqueue(p.dt, 1, 0, advance=False)
+    _, idx, xr, yr, _, _ = g.resident_read()
+    want_idx, wxr, wyr, _ = amd.calc_ref_path(px2, py2, px2[-3], 0.0, p.v_ref, p.dt, 0.1, p.horizon)
+    assert idx == want_idx == len(px2) - 3
+    np.testing.assert_array_equal(xr, wxr)
+    assert xr[-1] == px2[-1] and xr[5] == px2[-1]
+
+
+def test_resident_partials_step_matches_plain_step():
+    """K-sharded form: [sum w, sum w*u] left in a device buffer, applied afterwards -- same u*, same poses."""
+    import torch
+    w = configs.workload("C2", num_samples=2048)
+    p = w.params
+    px, py = amd.make_path(w.path)
+    s0 = start(p, px, py)
+    a, b = MPPIController(p), MPPIController(p)
+    vec = torch.zeros(b.partials_size(), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for g in (a, b):
+        g.resident_set_path(px, py)
+        g.resident_set_pose(s0)
+    for it in range(6):
+        a.resident_step_enqueue(p.dt, 9, it, advance=it > 0)
+        b.resident_step_partials_enqueue(p.dt, 9, it, it > 0, vec.data_ptr())
+        b.apply_partials_enqueue(vec.data_ptr())
+    np.testing.assert_array_equal(a.resident_read()[0], b.resident_read()[0])
+    np.testing.assert_allclose(a.get_nominal(), b.get_nominal(), rtol=1e-12, atol=0)
+
+
+def test_resident_errors():
+    p = configs.diff_drive_defaults(256, 30)
+    g = MPPIController(p)
+    with pytest.raises(MPPIError):
+        g.resident_step_enqueue(p.dt, 1, 0)          # no path
+    with pytest.raises(MPPIError):
+        g.resident_set_pose([0, 0, 0])               # no path yet
+    px, py = amd.make_path("straight")
+    with pytest.raises(MPPIError):
+        g.resident_set_path(px, py, 0.0)             # resolution
+    g.resident_set_path(px, py, 0.1)
+    with pytest.raises(MPPIError):
+        g.resident_step_enqueue(p.dt, 1, 0)          # no pose
+    g.resident_set_pose([0, 0, 0])
+    with pytest.raises(MPPIError):
+        g.resident_step_enqueue(float("nan"), 1, 0)
+    g.resident_step_enqueue(p.dt, 1, 0, advance=False)
+    assert np.all(np.isfinite(g.get_nominal()))

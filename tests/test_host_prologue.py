@@ -45,4 +45,8 @@ def test_plant_step_matches_predict_next_state(model, n):
     rng = np.random.default_rng(2)
     for _ in range(20):
         s, u = rng.normal(size=n), rng.normal(size=5)
-        np.testing.assert_array_equal(amd.plant_step(model, s, u, 0.1), helpers.plant(model, s, u, 0.1))
+        # sin / cos of the heading are the device's specified polynomial evaluation (<= 1 ulp from libm), so that the host
+        # plant and the resident loop's plant (tests/test_gpu_resident.py) give the same bits
+        np.testing.assert_allclose(amd.plant_step(model, s, u, 0.1), helpers.plant(model, s, u, 0.1), rtol=0, atol=1e-15)
+    with pytest.raises(amd.controller.MPPIError):
+        amd.plant_step(model, np.array([0.0, 0.0, 2.0e5, 0.0, 0.0][:n]), np.zeros(5), 0.1)   # outside the specified range
