@@ -5,6 +5,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/c2_bench.json 2> $O/c2_bench.err
 for w in C3 C4; do python3 $R/bench.py --workload $w --steps 100 --warmup 10 --no-cpu-baseline > $O/${w}_bench.json 2>/dev/null; done
+python3 $R/bench.py --closed-loop --no-cpu-baseline > $O/c2_closed_loop_bench.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/c2_bench_under_rocprof.json 2> $O/ktrace.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-events > /dev/null 2> $O/pmc_w.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-events > /dev/null 2> $O/pmc_f.err
