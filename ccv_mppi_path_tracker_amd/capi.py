@@ -98,6 +98,7 @@ SIGNATURES = {
     "ccv_mppi_node_set_state": (C.c_int, [_H, _dp]),
     "ccv_mppi_node_set_seed": (C.c_int, [_H, C.c_uint64]),
     "ccv_mppi_node_set_fused": (C.c_int, [_H, C.c_int]),
+    "ccv_mppi_node_set_device_prologue": (C.c_int, [_H, C.c_int]),
     "ccv_mppi_node_run_once": (C.c_int, [_H, C.c_double, _dp]),
     "ccv_mppi_node_get_optimal": (C.c_int, [_H, _dp]),
     "ccv_mppi_node_get_ref_path": (C.c_int, [_H, _dp]),

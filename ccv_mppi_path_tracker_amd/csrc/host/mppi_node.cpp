@@ -43,6 +43,7 @@ void MPPIBase::create_handle(const ccv_mppi_config& cfg) {
 
 void MPPIBase::pathCallback(const Path& msg) {
     path_ = msg;
+    path_uploaded_ = false;
     if (!path_received_) path_received_ = true;
 }
 
@@ -85,7 +86,25 @@ void MPPIBase::publish_CmdVel() {
 bool MPPIBase::run_once(double dt) {
     if (!path_received_) return false;
     dt_ = dt;   // the reference overwrites dt_ with the measured loop period every pass (dd:346-348)
-    if (use_fused_) {
+    if (use_fused_ && device_prologue_) {
+        // the window is built where it is used: pose in, one launch sequence, u* (and the window, for get_ref_path) out
+        const double x0[5] = {current_state_.x, current_state_.y, current_state_.yaw, current_state_.roll, current_state_.pitch};
+        last_status_ = CCV_MPPI_OK;
+        if (!path_uploaded_) {
+            last_status_ = ccv_mppi_resident_set_path(handle_, path_.x.data(), path_.y.data(), (int32_t)path_.size(), resolution_);
+            path_uploaded_ = last_status_ == CCV_MPPI_OK;
+        }
+        if (last_status_ == CCV_MPPI_OK) last_status_ = ccv_mppi_resident_set_pose(handle_, x0);
+        if (last_status_ == CCV_MPPI_OK) last_status_ = ccv_mppi_resident_step_enqueue(handle_, dt_, seed_, iteration_, 0);
+        if (last_status_ == CCV_MPPI_OK) last_status_ = ccv_mppi_get_nominal(handle_, optimal_solution.data());
+        int32_t idx = 0;
+        if (last_status_ == CCV_MPPI_OK)
+            last_status_ = ccv_mppi_resident_read(handle_, nullptr, &idx, x_ref_.data(), y_ref_.data(), &yaw_ref_[0], nullptr);
+        current_index_ = idx;
+        // yaw_ref_[1..] is not needed by the iteration (fb:408 reads element 0 only); publish_RefPath()'s mirror derives
+        // it from the window like calc_RefPath() does (dd:176-179)
+        for (int i = 1; i + 1 < horizon_; ++i) yaw_ref_[i] = std::atan2(y_ref_[i + 1] - y_ref_[i], x_ref_[i + 1] - x_ref_[i]);
+    } else if (use_fused_) {
         calc_RefPath();
         const double x0[5] = {current_state_.x, current_state_.y, current_state_.yaw, current_state_.roll, current_state_.pitch};
         last_status_ = ccv_mppi_iterate(handle_, x0, dt_, x_ref_.data(), y_ref_.data(), yaw_ref_[0], seed_, iteration_,
@@ -375,6 +394,12 @@ int ccv_mppi_node_set_seed(ccv_mppi_node_t* node, uint64_t seed) {
 int ccv_mppi_node_set_fused(ccv_mppi_node_t* node, int fused) {
     if (!node) return CCV_MPPI_ERR_INVALID_ARG;
     node->impl->use_fused_ = fused != 0;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_node_set_device_prologue(ccv_mppi_node_t* node, int on) {
+    if (!node) return CCV_MPPI_ERR_INVALID_ARG;
+    node->impl->device_prologue_ = on != 0;
     return CCV_MPPI_OK;
 }
 

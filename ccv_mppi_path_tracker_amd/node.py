@@ -12,7 +12,7 @@ from .controller import MPPIError
 class ControllerNode:
     """One controller node: set the path and the current state, then run_once(dt) = one pass of run() (dd:346-361)."""
 
-    def __init__(self, model, params=None, device=0, seed=42, fused=True):
+    def __init__(self, model, params=None, device=0, seed=42, fused=True, device_prologue=False):
         self.lib = capi.load()
         self.model = model
         self.udim, self.nstate = UDIM[model], NSTATE[model]
@@ -28,6 +28,7 @@ class ControllerNode:
             raise MPPIError(rc, "ccv_mppi_node_create failed -- no usable HIP device? (there is no CPU fallback)")
         self.lib.ccv_mppi_node_set_seed(self._h, int(seed))
         self.lib.ccv_mppi_node_set_fused(self._h, 1 if fused else 0)
+        self.lib.ccv_mppi_node_set_device_prologue(self._h, 1 if device_prologue else 0)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -38,6 +38,16 @@ class ShardedMPPI:
         self.backend.apply(part)
         return part
 
+    def iterate_resident(self, dt, seed, iteration, advance=True):
+        """The device-resident closed loop, K sharded: every rank holds the same path and pose (backend.resident_setup),
+        advances the pose with the same u* and builds the same window; only the partial vector crosses the links.
+        backend.local_partials_resident(dt, seed, iteration, advance) -> tensor as local_partials."""
+        part = self.backend.local_partials_resident(dt, seed, iteration, advance)
+        if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
+            self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.backend.apply(part)
+        return part
+
 
 class DevicePartials:
     """GPU backend: the partials live in a torch tensor on the controller's device; everything is enqueued on the
@@ -52,6 +62,14 @@ class DevicePartials:
 
     def local_partials(self, x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration):
         self.ctl.iterate_partials_enqueue(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration, self.buf.data_ptr())
+        return self.buf
+
+    def resident_setup(self, path_x, path_y, state, resolution=None):
+        self.ctl.resident_set_path(path_x, path_y, resolution)
+        self.ctl.resident_set_pose(state)
+
+    def local_partials_resident(self, dt, seed, iteration, advance):
+        self.ctl.resident_step_partials_enqueue(dt, seed, iteration, advance, self.buf.data_ptr())
         return self.buf
 
     def apply(self, reduced):

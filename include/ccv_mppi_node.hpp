@@ -79,6 +79,9 @@ public:
     int num_samples() const { return (int)num_samples_; }
     int udim() const { return udim_; }
     bool use_fused_ = true;   // run_once(): one fused device iteration (default) or the four stage-wise calls
+    // run_once() with use_fused_: get_CurrentIndex() + calc_RefPath() on the device (ccv_mppi_resident_*): the path is
+    // uploaded once by pathCallback(), a tick sends the measured pose and receives u* and the window it was planned on
+    bool device_prologue_ = false;
 
 protected:
     MPPIBase(int model, const ParamMap& params, int device);
@@ -98,6 +101,7 @@ protected:
     double tread_ = 0.501, wheel_radius_ = 0.1435;
     // state
     Path path_;
+    bool path_uploaded_ = false;   // device_prologue_: the current path_ is in HBM
     RobotState current_state_;
     bool path_received_ = false;
     int current_index_ = 0;
@@ -138,6 +142,7 @@ int ccv_mppi_node_set_path(ccv_mppi_node_t* node, const double* x, const double*
 int ccv_mppi_node_set_state(ccv_mppi_node_t* node, const double* state5);
 int ccv_mppi_node_set_seed(ccv_mppi_node_t* node, uint64_t seed);
 int ccv_mppi_node_set_fused(ccv_mppi_node_t* node, int fused);
+int ccv_mppi_node_set_device_prologue(ccv_mppi_node_t* node, int on);   /* window built on the device (fused mode only) */
 /* one run() pass; returns 1 if a command was produced, 0 while waiting for the path, <0 on error.
  * cmd_out: linear.x, angular.z, steer_l, steer_r, fore, rear, roll */
 int ccv_mppi_node_run_once(ccv_mppi_node_t* node, double dt, double* cmd_out7);

@@ -39,6 +39,17 @@ class OraclePartials:
         r = reduced.numpy()
         self.o.set_nominal((r[1:] / r[0]).reshape(self.p.horizon - 1, self.p.udim))
 
+    # the resident closed loop (ShardedMPPI.iterate_resident): path and pose held by the backend, prologue per tick
+    def resident_setup(self, path, state):
+        self.path, self.state = path, np.array(state, dtype=np.float64)
+
+    def local_partials_resident(self, dt, seed, iteration, advance):
+        import helpers
+        if advance:
+            self.state = helpers.plant(self.p.model, self.state, self.o.get_nominal()[0], dt)
+        xr, yr, yaw = helpers.oracle_window(self.p, self.path, self.state)
+        return self.local_partials(self.state, dt, xr, yr, yaw[0], seed, iteration)
+
 
 def _free_port():
     s = socket.socket()
@@ -48,7 +59,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, model, out_path):
+def _worker(rank, world, port, model, out_path, resident=False):
     import helpers
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -60,9 +71,14 @@ def _worker(rank, world, port, model, out_path):
     state = np.zeros(p.nstate)
     state[:2] = path[0][0], path[1][0] + 0.05
     outs = []
+    if resident:
+        drv.backend.resident_setup(path, state)
     for it in range(3):
-        xr, yr, yaw = helpers.oracle_window(p, path, state)
-        drv.iterate(state, p.dt, xr, yr, yaw[0], 11, it)
+        if resident:   # pose and window are the backend's business
+            drv.iterate_resident(p.dt, 11, it, advance=it > 0)
+        else:
+            xr, yr, yaw = helpers.oracle_window(p, path, state)
+            drv.iterate(state, p.dt, xr, yr, yaw[0], 11, it)
         u = drv.backend.o.get_nominal()
         outs.append(u)
         state = helpers.plant(p.model, state, u[0], p.dt)
@@ -77,11 +93,11 @@ def _worker(rank, world, port, model, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model", ["C2", "C4"])
-def test_two_gloo_ranks_reproduce_single_rank(tmp_path, model):
+@pytest.mark.parametrize("model,resident", [("C2", False), ("C4", False), ("C2", True)])
+def test_two_gloo_ranks_reproduce_single_rank(tmp_path, model, resident):
     import helpers
     out = str(tmp_path / "u.npy")
-    mp.spawn(_worker, args=(2, _free_port(), model, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), model, out, resident), nprocs=2, join=True)
     got = np.load(out)
     # single rank, same global sample ids
     w = configs.workload(model, num_samples=256, horizon=20)

@@ -93,6 +93,36 @@ def test_stagewise_and_fused_nodes_agree(model, kind, over):
         s = amd.plant_step(model, s, a.optimal_solution()[0], 0.1)
 
 
+@pytest.mark.parametrize("model,kind,over", CASES)
+def test_device_prologue_node_agrees_with_host_prologue_node(model, kind, over):
+    """run_once() with get_CurrentIndex() + calc_RefPath() on the device (ccv_mppi_resident_*): same window, same u*, same
+    commands; full body within rounding (yaw_ref[0] from the device atan2 enters fb:408)."""
+    px, py = amd.make_path(kind)
+    a, b = ControllerNode(model, over, seed=3), ControllerNode(model, over, seed=3, device_prologue=True)
+    s = np.zeros(configs.NSTATE[model])
+    s[:2] = px[0], py[0] + 0.1
+    for n in (a, b):
+        n.set_path(px, py)
+    for it in range(5):
+        for n in (a, b):
+            n.set_state(s)
+        ra, rb = a.run_once(0.1), b.run_once(0.1)
+        np.testing.assert_array_equal(a.ref_path()[:, :2], b.ref_path()[:, :2])
+        np.testing.assert_allclose(a.ref_path()[:-1, 2], b.ref_path()[:-1, 2], rtol=0, atol=1e-15)
+        if model == "full_body":
+            np.testing.assert_allclose(a.optimal_solution(), b.optimal_solution(), rtol=1e-9, atol=1e-12)
+        else:
+            np.testing.assert_array_equal(a.optimal_solution(), b.optimal_solution())
+            assert ra == rb
+        s = amd.plant_step(model, s, a.optimal_solution()[0], 0.1)
+    if it == 4:   # a new path replaces the uploaded one
+        for n in (a, b):
+            n.set_path(px[::-1].copy(), py[::-1].copy())
+            n.set_state(s)
+        a.run_once(0.1), b.run_once(0.1)
+        np.testing.assert_array_equal(a.ref_path()[:, :2], b.ref_path()[:, :2])
+
+
 def test_cmd_pos_post_processing():
     tread = 0.501
     px, py = amd.make_path("sinusoid")

@@ -147,6 +147,38 @@ def test_resident_partials_step_matches_plain_step():
     np.testing.assert_allclose(a.get_nominal(), b.get_nominal(), rtol=1e-12, atol=0)
 
 
+def test_resident_sharded_driver_two_shards_one_device():
+    """ShardedMPPI.iterate_resident over two shards of K held by two handles on this device (the all-reduce done by hand):
+    same poses and u* as one handle with all K, to summation order."""
+    import torch
+    from ccv_mppi_path_tracker_amd import sharded
+    w = configs.workload("C2", num_samples=2048)
+    p = w.params
+    px, py = amd.make_path(w.path)
+    s0 = start(p, px, py)
+    whole = MPPIController(p)
+    whole.resident_set_path(px, py)
+    whole.resident_set_pose(s0)
+    # a dedicated torch stream, as bench.py does: DevicePartials puts its handle on torch's current stream, so the handles'
+    # kernels and the stand-in for the all-reduce below are ordered (the null stream would mean "the handle's own stream")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        halves = [sharded.DevicePartials(MPPIController(p, num_samples=1024, sample_offset=o)) for o in (0, 1024)]
+        for h in halves:
+            h.resident_setup(px, py, s0)
+        for it in range(8):
+            whole.resident_step_enqueue(p.dt, 3, it, advance=it > 0)
+            parts = [h.local_partials_resident(p.dt, 3, it, it > 0) for h in halves]
+            total = parts[0] + parts[1]
+            for h in halves:
+                h.apply(total)
+                h.ctl.synchronize()   # (total is a temporary: apply now instead of deferring)
+    want = whole.resident_read()[0]
+    for h in halves:
+        np.testing.assert_allclose(h.ctl.resident_read()[0], want, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(h.ctl.get_nominal(), whole.get_nominal(), rtol=1e-9, atol=1e-12)
+
+
 def test_resident_errors():
     p = configs.diff_drive_defaults(256, 30)
     g = MPPIController(p)
