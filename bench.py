@@ -104,6 +104,10 @@ def main():
     ap.add_argument("--closed-loop", action="store_true",
                     help="not the headline: the device-resident closed loop (pose advanced by u*[0] and the window rebuilt "
                          "on the device every step; the workload's path generator with the course extended so that it never ends)")
+    ap.add_argument("--exchange", default=os.environ.get("CCV_MPPI_EXCHANGE", "auto"), choices=["auto", "p2p", "rccl"],
+                    help="N > 1: how the partial vectors meet -- p2p: written straight into the peers' HBM by the update "
+                         "kernel (one node); rccl: one all-reduce per iteration; auto: p2p when it can be set up and "
+                         "reproduces the all-reduce result, else rccl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-state-store", action="store_true", help="skip the KxH x,y buffer (not the headline)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel hipEvents in the timed region")
@@ -155,7 +159,64 @@ def main():
     inputs = script_inputs(amd, w, 64)
     seed = 42
     # N > 1: per-GPU partials [sum w, sum w*u] -> one small RCCL all-reduce over xGMI -> every rank divides (no host sync)
-    driver = sharded.ShardedMPPI(sharded.DevicePartials(ctl)) if world > 1 else None
+    driver, exchange_used = None, None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world > 1:
+        rccl = sharded.ShardedMPPI(sharded.DevicePartials(ctl))
+        driver, exchange_used = rccl, "rccl all-reduce"
+        if args.exchange != "rccl":
+            xb = sharded.ExchangeBackend(ctl)
+            good = xb.ok
+            direct = sharded.ShardedMPPI(xb) if good else None
+            zeros = np.zeros((p.horizon - 1, p.udim))
+
+            def run(drv, n):
+                for i in range(n):
+                    s0, xr0, yr0, yaw00 = inputs[i % len(inputs)]
+                    drv.iterate(s0, p.dt, xr0, yr0, yaw00, seed, i)
+
+            if good:
+                # both ways on the same inputs from the same warm start: the direct exchange is considered only if it
+                # reproduces the all-reduce result on every rank (rank-order vs ring-order sums: rounding only)
+                got = []
+                for drv in (direct, rccl):
+                    ctl.set_nominal(zeros)
+                    run(drv, 3)
+                    got.append(ctl.get_nominal())
+                good = bool(np.all(np.isfinite(got[0])) and np.allclose(got[0], got[1], rtol=1e-9, atol=1e-12))
+            flags = [None] * world
+            dist.all_gather_object(flags, good)
+            if all(flags):
+                # ... and used only if it is also the faster one on this node (slowest rank decides)
+                took = []
+                for drv in (direct, rccl):
+                    run(drv, 1024)   # (the first several hundred launches of a process are slow on the host)
+                    fence()
+                    t_sel = time.perf_counter()
+                    run(drv, 256)
+                    fence()
+                    t = torch.tensor([time.perf_counter() - t_sel], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    took.append(float(t.item()))
+                ctl.set_nominal(zeros)
+                if took[0] <= took[1] or args.exchange == "p2p":
+                    driver = direct
+                    exchange_used = "direct stores into the peers' HBM (hipIpc over xGMI), rank-order sum"
+                exchange_used += " [256 steps: direct %.1f us/step, rccl %.1f us/step]" % (took[0] / 256 * 1e6, took[1] / 256 * 1e6)
+            elif args.exchange == "p2p":
+                print("bench.py: --exchange p2p could not be set up or verified: %s" % getattr(xb, "error", flags), file=sys.stderr)
+                sys.exit(5)
+    elif args.exchange == "p2p":   # N = 1: the exchange kernel talking to itself (its overhead over k_finalize)
+        xb = sharded.ExchangeBackend(ctl)
+        if not xb.ok:
+            print("bench.py: --exchange p2p could not be set up: %s" % getattr(xb, "error", ""), file=sys.stderr)
+            sys.exit(5)
+        driver, exchange_used = sharded.ShardedMPPI(xb), "direct exchange, one rank"
 
     if args.closed_loop:
         if world > 1:
@@ -174,15 +235,10 @@ def main():
             ctl.resident_step_enqueue(p.dt, seed, i, advance=True)
             return
         s, xr, yr, yaw0 = inputs[i % len(inputs)]
-        if world == 1:
+        if driver is None:
             ctl.iterate_enqueue(s, p.dt, xr, yr, yaw0, seed, i)
         else:
             driver.iterate(s, p.dt, xr, yr, yaw0, seed, i)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # Set-up, not part of the warm-up count: for the first several hundred launches of a process the host side of a
     # launch is several times slower on some boxes (runtime pools growing, host and device clocks ramping; measured with
@@ -241,7 +297,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s, u_dim=%d, launch parameters" % (w.name, w.description.replace(
                 "K=%d" % p.num_samples, "K=%d" % k_total), p.udim),
-                       "samples_per_gpu": k_local, "horizon": p.horizon, "sharding": "K over %d GPU(s)" % world,
+                       "samples_per_gpu": k_local, "horizon": p.horizon, "sharding": "K over %d GPU(s)" % world, **({"exchange": exchange_used} if exchange_used else {}),
                        "state_store": not args.no_state_store,
                        **({"closed_loop": "device-resident: plant + get_CurrentIndex + calc_RefPath on the device, "
                                           "%d path poses" % len(cl_px)} if args.closed_loop else {})},

@@ -76,6 +76,10 @@ SIGNATURES = {
     "ccv_mppi_iterate_partials_enqueue": (C.c_int, [_H, _dp, C.c_double, _dp, _dp, C.c_double, C.c_uint64,
                                                     C.c_uint64, C.c_void_p]),
     "ccv_mppi_apply_partials_enqueue": (C.c_int, [_H, C.c_void_p]),
+    "ccv_mppi_exchange_handle_bytes": (C.c_int, []),
+    "ccv_mppi_exchange_create": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p]),
+    "ccv_mppi_exchange_connect": (C.c_int, [_H, C.c_void_p]),
+    "ccv_mppi_iterate_exchange_enqueue": (C.c_int, [_H, _dp, C.c_double, _dp, _dp, C.c_double, C.c_uint64, C.c_uint64]),
     "ccv_mppi_resident_set_path": (C.c_int, [_H, _dp, _dp, C.c_int32, C.c_double]),
     "ccv_mppi_resident_set_pose": (C.c_int, [_H, _dp]),
     "ccv_mppi_resident_step_enqueue": (C.c_int, [_H, C.c_double, C.c_uint64, C.c_uint64, C.c_int32]),

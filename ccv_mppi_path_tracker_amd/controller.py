@@ -177,6 +177,24 @@ class MPPIController:
     def apply_partials_enqueue(self, dev_ptr):
         self._check(self.lib.ccv_mppi_apply_partials_enqueue(self._h, C.c_void_p(dev_ptr)))
 
+    # ---- direct exchange between the devices of one node (no collective call per iteration) ----
+    def exchange_create(self, world, rank):
+        """-> the IPC handle (bytes) of this device's box, to be gathered from all ranks."""
+        buf = C.create_string_buffer(self.lib.ccv_mppi_exchange_handle_bytes())
+        self._check(self.lib.ccv_mppi_exchange_create(self._h, int(world), int(rank), C.cast(buf, C.c_void_p)))
+        return bytes(buf.raw)
+
+    def exchange_connect(self, handles):
+        blob = b"".join(handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        self._check(self.lib.ccv_mppi_exchange_connect(self._h, C.cast(buf, C.c_void_p)))
+
+    def iterate_exchange_enqueue(self, x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration):
+        x = self._x0(x0)
+        xr, yr = capi.as_f64(x_ref, (self.H,)), capi.as_f64(y_ref, (self.H,))
+        self._check(self.lib.ccv_mppi_iterate_exchange_enqueue(
+            self._h, capi.dptr(x), float(dt), capi.dptr(xr), capi.dptr(yr), float(yaw_ref0), int(seed), int(iteration)))
+
     # ---- device-resident closed loop (get_CurrentIndex + calc_RefPath + plant on the device; SURVEY.md 8f n2) ----
     def resident_set_path(self, path_x, path_y, resolution=None):
         px, py = capi.as_f64(path_x), capi.as_f64(path_y)

@@ -49,6 +49,14 @@ struct ccv_mppi_handle {
     bool have_pose = false;
     int64_t res_steps = 0;                 // k_advance launches since the pose was set
     double res_angle_abs[3] = {0, 0, 0};   // conservative bounds on |yaw|, |roll|, |pitch| of the resident pose (fast_trig_safe)
+    // direct exchange of the partial vectors between the devices of a node (k_finalize_exchange, mppi_kernels.h)
+    ExchangeBox* d_box = nullptr;                   // this device's box (peers write into it)
+    ExchangeBox* box_peer[kMaxRanks] = {nullptr};   // every rank's box as mapped here ([xchg_rank] = d_box)
+    bool box_opened[kMaxRanks] = {false};           // mapped with hipIpcOpenMemHandle (to be closed)
+    double* d_xvec = nullptr;                       // reduced [sum w, sum w*u]
+    int xchg_world = 0, xchg_rank = 0;
+    bool xchg_connected = false;
+    unsigned long long xchg_seq = 0;
     // queue-depth throttle for the asynchronous entry points: beyond a few dozen iterations in flight the HIP runtime's
     // enqueue path slows down several-fold (measured: 12 us/call at depth <= 64, 90 us/call at depth 512), so every
     // kThrottleEvery-th enqueue records an event and waits for the one recorded kThrottleSlots marks earlier
@@ -298,7 +306,7 @@ int launch_sample(ccv_mppi_handle* h, const RolloutArgs& A) {
 }
 
 // weights -> [sum w, sum w*u] (-> u* when `normalise`); vec_out may be a caller-owned device buffer.
-int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out) {
+int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out, bool exchange = false) {
     int nparts = h->nparts_last;
     if (nparts == 0) {
         // not fused (one-sample-per-lane fallback kernel or MIN_SHIFT): stream w and the controls once more
@@ -329,6 +337,22 @@ int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out) {
     F.R = h->R;
     F.nchunks = nparts;
     F.normalise = normalise ? 1 : 0;
+    if (exchange) {
+        ExchangeArgs X;
+        for (int r = 0; r < kMaxRanks; ++r) X.peer[r] = h->box_peer[r];
+        X.local = h->d_box;
+        X.reduced = h->d_xvec;
+        ++h->xchg_seq;
+        X.seq = (uint32_t)(h->xchg_seq % 0xFFFFFFFFull) + 1u;   // 1 .. 2^32-1, never 0 (the box starts zeroed)
+        X.world = h->xchg_world;
+        X.rank = h->xchg_rank;
+        X.parity = (int)(h->xchg_seq & 1);
+        X.timeout_ticks = 1000000000ull;   // 10 s of the 100 MHz clock: a peer that never arrives yields NaN, not a hang
+        hipLaunchKernelGGL(k_finalize_exchange, dim3((h->R + 1 + 3) / 4), dim3(kBlock), 0, h->stream, F, X);
+        HIP_TRY(h, hipGetLastError());
+        h->pending_vec = h->d_xvec;   // u* = reduced[1..] / reduced[0]: deferred like ccv_mppi_apply_partials_enqueue
+        return CCV_MPPI_OK;
+    }
     hipLaunchKernelGGL(k_finalize, dim3((h->R + 1 + 3) / 4), dim3(kBlock), 0, h->stream, F);
     HIP_TRY(h, hipGetLastError());
     return CCV_MPPI_OK;
@@ -375,7 +399,8 @@ int check_iter_args(ccv_mppi_handle* h, const double* x0, double dt, const doubl
 // (resident: the pose and the window are taken from h->d_frame on the device; x0 then carries only the bounds on the pose
 //  angles that fast_trig_safe() needs, and x_ref / y_ref are not read)
 int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref, const double* y_ref,
-                      double yaw_ref0, uint64_t seed, uint64_t iter, bool normalise, double* vec_out, bool resident = false) {
+                      double yaw_ref0, uint64_t seed, uint64_t iter, bool normalise, double* vec_out, bool resident = false,
+                      bool exchange = false) {
     RolloutArgs A;
     Window W;
     fill_args(h, A, x0, dt, yaw_ref0, seed, iter);
@@ -403,7 +428,7 @@ int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const dou
     int rc = launch_rollout(h, A, W, MODE_FUSED);
     h->ev_kernel_start = h->ev_kernel_stop = nullptr;
     if (rc) return rc;
-    rc = launch_update(h, normalise, vec_out);
+    rc = launch_update(h, normalise, vec_out, exchange);
     if (rc) return rc;
     if (timed) HIP_TRY(h, hipEventRecord(h->ev[slot + 2], h->stream));
     if (h->throttle && ++h->enqueued % ccv_mppi_handle::kThrottleEvery == 0) {
@@ -648,6 +673,76 @@ int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partia
     if (rc) return rc;
     h->pending_vec = dev_partials;
     return CCV_MPPI_OK;
+}
+
+// ---- direct exchange between the devices of a node ------------------------------------------------------------------
+
+int ccv_mppi_exchange_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+int ccv_mppi_exchange_create(ccv_mppi_handle* h, int32_t world, int32_t rank, void* ipc_handle_out) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!ipc_handle_out || world < 1 || world > kMaxRanks || rank < 0 || rank >= world)
+        return fail(h, CCV_MPPI_ERR_INVALID_ARG, "exchange: 1 <= world <= 8, 0 <= rank < world");
+    if (h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT)
+        return fail(h, CCV_MPPI_ERR_INVALID_ARG, "MIN_SHIFT needs a cross-device min; not supported with partials");
+    if (h->d_box) return fail(h, CCV_MPPI_ERR_STATE, "exchange already created");
+    // fine-grained (not cached across devices) when the allocation can be exported; otherwise ordinary device memory,
+    // which the kernel reads past the caches anyway
+    void* box = nullptr;
+    hipIpcMemHandle_t ipc;
+    hipError_t e = hipExtMallocWithFlags(&box, sizeof(ExchangeBox), hipDeviceMallocFinegrained);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&ipc, box);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (box) (void)hipFree(box);
+        box = nullptr;
+        HIP_TRY(h, hipMalloc(&box, sizeof(ExchangeBox)));
+        e = hipIpcGetMemHandle(&ipc, box);
+        if (e != hipSuccess) {
+            (void)hipFree(box);
+            return fail(h, CCV_MPPI_ERR_HIP, "hipIpcGetMemHandle failed: no peer mapping on this system");
+        }
+    }
+    HIP_TRY(h, hipMemset(box, 0, sizeof(ExchangeBox)));
+    h->d_box = static_cast<ExchangeBox*>(box);
+    HIP_TRY(h, hipMalloc(&h->d_xvec, (size_t)(h->R + 1) * sizeof(double)));
+    HIP_TRY(h, hipMemset(h->d_xvec, 0, (size_t)(h->R + 1) * sizeof(double)));
+    HIP_TRY(h, hipDeviceSynchronize());
+    h->xchg_world = world;
+    h->xchg_rank = rank;
+    h->xchg_seq = 0;
+    std::memcpy(ipc_handle_out, &ipc, sizeof(ipc));
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_exchange_connect(ccv_mppi_handle* h, const void* ipc_handles) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!ipc_handles) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "ipc_handles is null");
+    if (!h->d_box) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_exchange_create first");
+    if (h->xchg_connected) return fail(h, CCV_MPPI_ERR_STATE, "exchange already connected");
+    const char* bytes = static_cast<const char*>(ipc_handles);
+    for (int r = 0; r < h->xchg_world; ++r) {
+        if (r == h->xchg_rank) {
+            h->box_peer[r] = h->d_box;
+            continue;
+        }
+        hipIpcMemHandle_t ipc;
+        std::memcpy(&ipc, bytes + (size_t)r * sizeof(ipc), sizeof(ipc));
+        void* p = nullptr;
+        HIP_TRY(h, hipIpcOpenMemHandle(&p, ipc, hipIpcMemLazyEnablePeerAccess));
+        h->box_peer[r] = static_cast<ExchangeBox*>(p);
+        h->box_opened[r] = true;
+    }
+    h->xchg_connected = true;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_iterate_exchange_enqueue(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref,
+                                      const double* y_ref, double yaw_ref0, uint64_t seed, uint64_t iter) {
+    int rc = check_iter_args(h, x0, dt, x_ref, y_ref);
+    if (rc) return rc;
+    if (!h->xchg_connected) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_exchange_create / _connect first");
+    return enqueue_iteration(h, x0, dt, x_ref, y_ref, yaw_ref0, seed, iter, false, nullptr, false, true);
 }
 
 // ---- device-resident closed loop (mppi_resident.h) ------------------------------------------------------------------

@@ -551,6 +551,107 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
     }
 }
 
+// ---- K sharded over the GPUs of one node without a collective library call ---------------------------
+// The exchanged message is 1 + (H-1)*u_dim doubles (<= 3.2 KB): far below the size at which a ring all-reduce pays, and a
+// collective kernel launch between two rollout launches costs more than the transfer.  Instead every device owns an
+// ExchangeBox in its HBM that all peers have mapped (hipIpc, xGMI peer access).  The wave of k_finalize_exchange that owns
+// a row writes its value straight into slot [rank][row] of every peer's box, waits for the peers' values of the same row
+// in its own box and adds them in rank order -- the same order on every device, so all devices hold the same bits.
+// A value travels as two self-validating 8-byte packets {32 data bits, 32-bit sequence number} (each an atomic store):
+// the receiver needs no flag and the sender no fence -- a packet is either the old one or the new one.  Two parities
+// alternate: a slot is rewritten two exchanges later, which a peer can only reach after it has received this device's
+// next packets, i.e. after this device's launch that read the slot has finished (stream order).
+constexpr int kMaxRanks = 8;
+constexpr int kMaxVec = 1 + (kMaxH - 1) * CCV_MPPI_MAX_UDIM;
+struct ExchangeBox {
+    unsigned long long pkt[2][kMaxRanks][kMaxVec][2];   // [parity][source rank][slot: 0 = sum w, 1 + row][high / low half]
+};
+struct ExchangeArgs {
+    ExchangeBox* peer[kMaxRanks];   // every rank's box as mapped on this device (peer[rank] = the local one)
+    ExchangeBox* local;
+    double* reduced;                // [1 + R]: sum over ranks, rank order (becomes the deferred warm-start update)
+    uint32_t seq;                   // this exchange's sequence number, never 0
+    int32_t world, rank, parity;
+    unsigned long long timeout_ticks;   // s_memrealtime ticks (100 MHz) to wait for the peers; then `reduced` is NaN
+};
+
+__device__ __forceinline__ unsigned long long load_system(const unsigned long long* p) {   // past every cache
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_finalize_exchange(const FinalizeArgs A, const ExchangeArgs X) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);   // rows 0..R-1; wave R: sum w and the cost statistics
+    if (n > A.R) return;
+    const int nrow = n < A.R ? n : A.R;
+    double s, v;
+    lane_partial_sum2(A.partial + (size_t)A.R * A.nchunks, A.partial + (size_t)nrow * A.nchunks, A.nchunks, lane, s, v);
+    s = wave_sum(s);
+    v = wave_sum(v);
+    // ---- this wave's value into slot [rank] of every peer's box: lane d writes to rank d
+    const int slot = n < A.R ? 1 + n : 0;
+    const double mine = n < A.R ? v : s;
+    if (lane < X.world) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+        unsigned long long* dst = &X.peer[lane]->pkt[X.parity][X.rank][slot][0];
+        __hip_atomic_store(dst + 0, (bits & 0xFFFFFFFF00000000ull) | X.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 1, (bits << 32) | X.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (n < A.R && lane == 0) A.vec[1 + n] = v;   // (this device's share, for ccv_mppi diagnostics)
+    if (n == A.R) {
+        double mn = INFINITY, mx = -INFINITY, nz = 0.0;
+        for (int c0 = 0; c0 < A.nchunks; c0 += 1024) {
+            double a[16], b[16], z[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = min(c0 + lane + 64 * i, A.nchunks - 1);
+                a[i] = A.statpart[c * 3 + 0];
+                b[i] = A.statpart[c * 3 + 1];
+                z[i] = A.statpart[c * 3 + 2];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool in = c0 + lane + 64 * i < A.nchunks;
+                mn = fmin(mn, in ? a[i] : INFINITY);
+                mx = fmax(mx, in ? b[i] : -INFINITY);
+                nz += in ? z[i] : 0.0;
+            }
+        }
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        nz = wave_sum(nz);
+        if (lane == 0) {
+            A.vec[0] = s;
+            A.stats[0] = s;   // (this device's share; the rollout that applies the reduced vector writes the global sum)
+            A.stats[1] = mn;
+            A.stats[2] = mx;
+            A.stats[3] = nz;
+        }
+    }
+    // ---- the peers' values of the same slot: lane r polls rank r's two packets in the local box
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long* src = &X.local->pkt[X.parity][lane < X.world ? lane : 0][slot][0];
+    unsigned long long hi = 0, lo = 0;
+    bool arrived = lane >= X.world;
+    while (true) {
+        if (!arrived) {
+            hi = load_system(src + 0);
+            lo = load_system(src + 1);
+            arrived = (uint32_t)hi == X.seq && (uint32_t)lo == X.seq;
+        }
+        if (__all(arrived)) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > X.timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    const bool ok = __all(arrived);
+    const double theirs = __longlong_as_double((long long)((hi & 0xFFFFFFFF00000000ull) | (lo >> 32)));
+    double acc = 0.0;
+    for (int r = 0; r < X.world; ++r) acc += lane_value(theirs, r);   // rank order on every device
+    if (lane == 0) X.reduced[slot] = ok ? acc : __builtin_nan("");
+}
+
 // After the cross-device all-reduce of [sum w, sum w*u]: u* = V / S on every device.
 __global__ __launch_bounds__(kBlock) void k_apply_partials(const double* vec, double* nominal, double* stats, int R) {
     const double S = vec[0];

@@ -32,6 +32,8 @@ class ShardedMPPI:
         self.group = group
 
     def iterate(self, x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration):
+        if hasattr(self.backend, "iterate"):   # the backend exchanges the partials itself (ExchangeBackend)
+            return self.backend.iterate(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration)
         part = self.backend.local_partials(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration)
         if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
             self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -74,6 +76,45 @@ class DevicePartials:
 
     def apply(self, reduced):
         self.ctl.apply_partials_enqueue(reduced.data_ptr())
+
+
+class ExchangeBackend:
+    """GPU backend for the devices of ONE node that needs no collective call per iteration: every device writes its
+    partial vector straight into a box in each peer's HBM (mapped once through hipIpc, xGMI peer access), the update kernel
+    waits for the peers' vectors and adds them in rank order (ccv_mppi_exchange_* in include/ccv_mppi.h).  The process
+    group is used once, to hand the IPC handles round.  `ok` is False when the boxes could not be created or mapped on
+    some rank -- every rank then sees False and the caller falls back to DevicePartials + all-reduce."""
+
+    def __init__(self, controller, group=None):
+        import torch
+        import torch.distributed as dist
+        self.ctl = controller
+        controller.set_stream(torch.cuda.current_stream().cuda_stream)
+        multi = dist.is_initialized() and dist.get_world_size(group) > 1
+        world = dist.get_world_size(group) if multi else 1
+        rank = dist.get_rank(group) if multi else 0
+        try:
+            mine = controller.exchange_create(world, rank)
+        except Exception as e:   # noqa: BLE001 -- any failure means "not available here"
+            mine, self.error = None, str(e)
+        handles = [mine]
+        if multi:
+            handles = [None] * world
+            dist.all_gather_object(handles, mine, group=group)
+        good = all(h is not None for h in handles)
+        if good:
+            try:
+                controller.exchange_connect(handles)
+            except Exception as e:   # noqa: BLE001
+                good, self.error = False, str(e)
+        if multi:
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(good), group=group)
+            good = all(flags)
+        self.ok = bool(good)
+
+    def iterate(self, x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration):
+        self.ctl.iterate_exchange_enqueue(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration)
 
 
 def combine_partials(parts):

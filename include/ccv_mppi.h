@@ -155,6 +155,20 @@ int ccv_mppi_iterate_partials_enqueue(ccv_mppi_handle* h, const double* x0, doub
  * unchanged until then, or until ccv_mppi_synchronize / ccv_mppi_get_nominal, which perform it at once. */
 int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partials);
 
+/* Same, without a collective-library call per iteration, for the devices of ONE node (world <= 8): each handle owns a
+ * small box in its HBM that the peers map (hipIpc over xGMI); the update kernel writes this device's partial vector
+ * straight into every peer's box, waits for the peers' vectors in its own and adds them in rank order (identical bits on
+ * every device); the division is deferred into the next rollout as above.  Set-up: every process calls _create, the
+ * processes exchange the returned handles (ccv_mppi_exchange_handle_bytes() bytes each, e.g. torch.distributed
+ * all_gather), then every process calls _connect with all of them in rank order.  Every rank must then issue the same
+ * sequence of ccv_mppi_iterate_exchange_enqueue calls; a peer that does not arrive within 10 s yields NaN controls, not a
+ * hang.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only supports dmabuf IPC. */
+int ccv_mppi_exchange_handle_bytes(void);
+int ccv_mppi_exchange_create(ccv_mppi_handle* h, int32_t world, int32_t rank, void* ipc_handle_out);
+int ccv_mppi_exchange_connect(ccv_mppi_handle* h, const void* ipc_handles);
+int ccv_mppi_iterate_exchange_enqueue(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref,
+                                      const double* y_ref, double yaw_ref0, uint64_t seed, uint64_t iter);
+
 /* ---- device-resident closed loop -------------------------------------------------- */
 /* The per-tick prologue of run() on the device: the whole reference path and the pose live in HBM, and every step does
  *   (advance != 0) pose <- pose advanced for dt by the command u*[0] of the previous step (the Euler model of

@@ -611,3 +611,79 @@ def test_closed_loop_matches_oracle_and_tracks():
     assert np.max(np.abs(s_g - s_o)) < 1e-6     # 60 feedback steps apart by rounding only
     assert s_g[0] > 1.5                        # made progress along the path
     assert np.sqrt(np.mean(np.square(errs[10:]))) < 0.5
+
+
+# --------------------------------------------------------------------------------------------------------------
+# direct exchange of the partial vectors (ccv_mppi_exchange_*): one process, and two processes sharing this device
+# --------------------------------------------------------------------------------------------------------------
+def test_exchange_single_rank_equals_plain_iteration():
+    """world = 1: the box is this device's own; the loop must follow ccv_mppi_iterate_enqueue (V/S from the same sums)."""
+    from ccv_mppi_path_tracker_amd import sharded
+    w = configs.workload("C2", num_samples=4096)
+    p = w.params
+    path = helpers.oracle_path(w.path)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    a, b = MPPIController(p), MPPIController(p)
+    xb = sharded.ExchangeBackend(b)
+    assert xb.ok
+    drv = sharded.ShardedMPPI(xb)
+    for it in range(5):
+        a.iterate_enqueue(state, p.dt, xr, yr, yaw[0], 5, it)
+        drv.iterate(state, p.dt, xr, yr, yaw[0], 5, it)
+    np.testing.assert_array_equal(a.get_nominal(), b.get_nominal())
+    with pytest.raises(MPPIError):
+        MPPIController(p).iterate_exchange_enqueue(state, p.dt, xr, yr, yaw[0], 5, 0)   # not connected
+
+
+def _exchange_worker(rank, world, port, K, iters, out_dir):
+    import torch
+    import torch.distributed as dist
+    from ccv_mppi_path_tracker_amd import sharded
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)   # both ranks on the one device of the box: the boxes are mapped across processes
+    w = configs.workload("C2", num_samples=K)
+    p = w.params
+    off, k_local = sharded.shard_bounds(K, world, rank)
+    ctl = MPPIController(p, num_samples=k_local, sample_offset=off)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        xb = sharded.ExchangeBackend(ctl)
+        assert xb.ok, getattr(xb, "error", "")
+        drv = sharded.ShardedMPPI(xb)
+        path = helpers.oracle_path(w.path)
+        state = start_state(p, path)
+        xr, yr, yaw = helpers.oracle_window(p, path, state)
+        for it in range(iters):
+            drv.iterate(state, p.dt, xr, yr, yaw[0], 5, it)
+        u = ctl.get_nominal()
+    np.save(os.path.join(out_dir, "u%d.npy" % rank), u)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_two_processes_on_one_device(tmp_path):
+    """Two ranks (processes) own half of K each and exchange their partial vectors through IPC-mapped boxes, 40 iterations
+    back to back (both parities, many reuses of the slots): both must end with the same bits, equal to the single-handle
+    loop up to summation order."""
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    K, iters = 4096, 40
+    mp.spawn(_exchange_worker, args=(2, port, K, iters, str(tmp_path)), nprocs=2, join=True)
+    u0, u1 = np.load(tmp_path / "u0.npy"), np.load(tmp_path / "u1.npy")
+    np.testing.assert_array_equal(u0, u1)
+    w = configs.workload("C2", num_samples=K)
+    p = w.params
+    path = helpers.oracle_path(w.path)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    whole = MPPIController(p)
+    for it in range(iters):
+        whole.iterate_enqueue(state, p.dt, xr, yr, yaw[0], 5, it)
+    np.testing.assert_allclose(u0, whole.get_nominal(), rtol=1e-7, atol=1e-10)
