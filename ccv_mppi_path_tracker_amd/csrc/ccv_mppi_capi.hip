@@ -732,6 +732,10 @@ int ccv_mppi_exchange_connect(ccv_mppi_handle* h, const void* ipc_handles) {
         HIP_TRY(h, hipIpcOpenMemHandle(&p, ipc, hipIpcMemLazyEnablePeerAccess));
         h->box_peer[r] = static_cast<ExchangeBox*>(p);
         h->box_opened[r] = true;
+        // touch the mapping through the runtime first: a mapping that cannot be used fails here with an error code
+        // instead of faulting in a kernel
+        unsigned long long probe = 0;
+        HIP_TRY(h, hipMemcpy(&probe, p, sizeof(probe), hipMemcpyDeviceToHost));
     }
     h->xchg_connected = true;
     return CCV_MPPI_OK;
