@@ -348,12 +348,12 @@ int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out, bool exch
         X.rank = h->xchg_rank;
         X.parity = (int)(h->xchg_seq & 1);
         X.timeout_ticks = 1000000000ull;   // 10 s of the 100 MHz clock: a peer that never arrives yields NaN, not a hang
-        hipLaunchKernelGGL(k_finalize_exchange, dim3((h->R + 1 + 3) / 4), dim3(kBlock), 0, h->stream, F, X);
+        hipLaunchKernelGGL(k_finalize_exchange, dim3(finalize_blocks(h->R)), dim3(kBlock), 0, h->stream, F, X);
         HIP_TRY(h, hipGetLastError());
         h->pending_vec = h->d_xvec;   // u* = reduced[1..] / reduced[0]: deferred like ccv_mppi_apply_partials_enqueue
         return CCV_MPPI_OK;
     }
-    hipLaunchKernelGGL(k_finalize, dim3((h->R + 1 + 3) / 4), dim3(kBlock), 0, h->stream, F);
+    hipLaunchKernelGGL(k_finalize, dim3(finalize_blocks(h->R)), dim3(kBlock), 0, h->stream, F);
     HIP_TRY(h, hipGetLastError());
     return CCV_MPPI_OK;
 }

@@ -504,11 +504,46 @@ __device__ __forceinline__ void lane_partial_sum2(const double* row_a, const dou
     sum_b = acc_b;
 }
 
+// min / max cost and the zero-weight count over the per-workgroup statistics: a wave of its own (n == R + 1), so that its
+// loads run beside the row reductions instead of after one of them
+__device__ __forceinline__ void finalize_cost_stats(const FinalizeArgs& A, const int lane) {
+    double mn = INFINITY, mx = -INFINITY, nz = 0.0;
+    for (int c0 = 0; c0 < A.nchunks; c0 += 1024) {
+        double a[16], b[16], z[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {   // all loads first: one memory latency per 1024 partials
+            const int c = min(c0 + lane + 64 * i, A.nchunks - 1);
+            a[i] = A.statpart[c * 3 + 0];
+            b[i] = A.statpart[c * 3 + 1];
+            z[i] = A.statpart[c * 3 + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool in = c0 + lane + 64 * i < A.nchunks;
+            mn = fmin(mn, in ? a[i] : INFINITY);
+            mx = fmax(mx, in ? b[i] : -INFINITY);
+            nz += in ? z[i] : 0.0;
+        }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    nz = wave_sum(nz);
+    if (lane == 0) {
+        A.stats[1] = mn;
+        A.stats[2] = mx;
+        A.stats[3] = nz;
+    }
+}
+constexpr int finalize_blocks(int R) { return (R + 2 + kBlock / 64 - 1) / (kBlock / 64); }   // waves: R rows, sum w, statistics
+
 __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
     const int lane = threadIdx.x & 63;
-    // rows 0..R-1: one wave each; the wave with n == R (first wave past the rows) gathers the cost statistics instead, so
-    // that their loads run beside the row reductions rather than after one of them
+    // rows 0..R-1: one wave each; wave R: sum w; wave R + 1: the cost statistics
     const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (n > A.R) {
+        if (n == A.R + 1) finalize_cost_stats(A, lane);
+        return;
+    }
     const int nrow = n < A.R ? n : A.R;
     // S = sum w and this wave's row are fetched together
     double s, v;
@@ -519,35 +554,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
         A.vec[1 + n] = v;
         if (A.normalise) A.nominal[n] = v / s;
     }
-    if (n == A.R) {
-        double mn = INFINITY, mx = -INFINITY, nz = 0.0;
-        for (int c0 = 0; c0 < A.nchunks; c0 += 1024) {
-            double a[16], b[16], z[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {   // all loads first: one memory latency per 1024 partials
-                const int c = min(c0 + lane + 64 * i, A.nchunks - 1);
-                a[i] = A.statpart[c * 3 + 0];
-                b[i] = A.statpart[c * 3 + 1];
-                z[i] = A.statpart[c * 3 + 2];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const bool in = c0 + lane + 64 * i < A.nchunks;
-                mn = fmin(mn, in ? a[i] : INFINITY);
-                mx = fmax(mx, in ? b[i] : -INFINITY);
-                nz += in ? z[i] : 0.0;
-            }
-        }
-        mn = wave_min(mn);
-        mx = wave_max(mx);
-        nz = wave_sum(nz);
-        if (lane == 0) {
-            A.vec[0] = s;
-            A.stats[0] = s;
-            A.stats[1] = mn;
-            A.stats[2] = mx;
-            A.stats[3] = nz;
-        }
+    if (n == A.R && lane == 0) {
+        A.vec[0] = s;
+        A.stats[0] = s;
     }
 }
 
@@ -583,8 +592,11 @@ __device__ __forceinline__ unsigned long long load_system(const unsigned long lo
 
 __global__ __launch_bounds__(kBlock) void k_finalize_exchange(const FinalizeArgs A, const ExchangeArgs X) {
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);   // rows 0..R-1; wave R: sum w and the cost statistics
-    if (n > A.R) return;
+    const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);   // rows 0..R-1; wave R: sum w; wave R + 1: cost statistics
+    if (n > A.R) {
+        if (n == A.R + 1) finalize_cost_stats(A, lane);   // (this device's samples only)
+        return;
+    }
     const int nrow = n < A.R ? n : A.R;
     double s, v;
     lane_partial_sum2(A.partial + (size_t)A.R * A.nchunks, A.partial + (size_t)nrow * A.nchunks, A.nchunks, lane, s, v);
@@ -599,36 +611,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize_exchange(const FinalizeArgs
         __hip_atomic_store(dst + 0, (bits & 0xFFFFFFFF00000000ull) | X.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(dst + 1, (bits << 32) | X.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (n < A.R && lane == 0) A.vec[1 + n] = v;   // (this device's share, for ccv_mppi diagnostics)
-    if (n == A.R) {
-        double mn = INFINITY, mx = -INFINITY, nz = 0.0;
-        for (int c0 = 0; c0 < A.nchunks; c0 += 1024) {
-            double a[16], b[16], z[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = min(c0 + lane + 64 * i, A.nchunks - 1);
-                a[i] = A.statpart[c * 3 + 0];
-                b[i] = A.statpart[c * 3 + 1];
-                z[i] = A.statpart[c * 3 + 2];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const bool in = c0 + lane + 64 * i < A.nchunks;
-                mn = fmin(mn, in ? a[i] : INFINITY);
-                mx = fmax(mx, in ? b[i] : -INFINITY);
-                nz += in ? z[i] : 0.0;
-            }
-        }
-        mn = wave_min(mn);
-        mx = wave_max(mx);
-        nz = wave_sum(nz);
-        if (lane == 0) {
-            A.vec[0] = s;
-            A.stats[0] = s;   // (this device's share; the rollout that applies the reduced vector writes the global sum)
-            A.stats[1] = mn;
-            A.stats[2] = mx;
-            A.stats[3] = nz;
-        }
+    if (lane == 0) {   // (this device's share)
+        A.vec[slot] = mine;
+        if (n == A.R) A.stats[0] = s;
     }
     // ---- the peers' values of the same slot: lane r polls rank r's two packets in the local box
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
