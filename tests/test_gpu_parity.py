@@ -664,10 +664,11 @@ def _exchange_worker(rank, world, port, K, iters, out_dir):
     dist.destroy_process_group()
 
 
-def test_exchange_two_processes_on_one_device(tmp_path):
-    """Two ranks (processes) own half of K each and exchange their partial vectors through IPC-mapped boxes, 40 iterations
-    back to back (both parities, many reuses of the slots): both must end with the same bits, equal to the single-handle
-    loop up to summation order."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_exchange_processes_on_one_device(tmp_path, world):
+    """2 / 4 ranks (processes) own an equal share of K each and exchange their partial vectors through IPC-mapped boxes,
+    40 iterations back to back (both parities, many reuses of the slots): all must end with the same bits, equal to the
+    single-handle loop up to summation order."""
     import torch.multiprocessing as mp
     import socket
     s = socket.socket()
@@ -675,9 +676,10 @@ def test_exchange_two_processes_on_one_device(tmp_path):
     port = s.getsockname()[1]
     s.close()
     K, iters = 4096, 40
-    mp.spawn(_exchange_worker, args=(2, port, K, iters, str(tmp_path)), nprocs=2, join=True)
-    u0, u1 = np.load(tmp_path / "u0.npy"), np.load(tmp_path / "u1.npy")
-    np.testing.assert_array_equal(u0, u1)
+    mp.spawn(_exchange_worker, args=(world, port, K, iters, str(tmp_path)), nprocs=world, join=True)
+    u0 = np.load(tmp_path / "u0.npy")
+    for r in range(1, world):
+        np.testing.assert_array_equal(u0, np.load(tmp_path / ("u%d.npy" % r)))
     w = configs.workload("C2", num_samples=K)
     p = w.params
     path = helpers.oracle_path(w.path)
