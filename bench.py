@@ -38,6 +38,20 @@ def algorithmic_bytes(T, udim):
     return whole, whole
 
 
+def rollout_kernel_name(model, k_local, device):
+    """The kernel ccv_mppi_create selects (csrc/ccv_mppi_capi.hip): more blocks of 64 samples than four per CU -> one wave
+    per block (k_rollout_solo); else the three-wave kernel, or the two-wave one for full body."""
+    forced = os.environ.get("CCV_MPPI_KERNEL")
+    if forced:
+        return {"v1": "k_rollout_cost", "pc": "k_rollout_pc", "r3": "k_rollout_pc" if model == "full_body" else "k_rollout_r3",
+                "solo": "k_rollout_solo"}.get(forced, forced)
+    import torch
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    if (k_local + 63) // 64 > 4 * cus:
+        return "k_rollout_solo"
+    return "k_rollout_pc" if model == "full_body" else "k_rollout_r3"
+
+
 def script_inputs(amd, w, n):
     """n (pose, window) pairs along the reference path: the robot advances ~v_ref*dt per step with a small lateral
     and heading offset, as a tracking controller would see them."""
@@ -303,7 +317,7 @@ def main():
                                           "%d path poses" % len(cl_px)} if args.closed_loop else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_rollout_pc" if p.model == "full_body" else "k_rollout_r3",
+                         "kernel": rollout_kernel_name(p.model, k_local, local_rank),
                          "kernel_avg_us": 1e6 * roll_avg_s,
                          "algorithmic_bytes_per_launch": B_roll * k_local,
                          "iteration_avg_us": 1e6 * iter_avg_s,

@@ -15,6 +15,7 @@
 #include "mppi_kernels.h"
 #include "mppi_rollout_pc.h"
 #include "mppi_rollout_r3.h"
+#include "mppi_rollout_solo.h"
 #include "mppi_resident.h"
 
 using namespace ccv;
@@ -78,6 +79,7 @@ struct ccv_mppi_handle {
     // CCV_MPPI_WINDOW=scalar -> its scalar-load window variant; default = k_rollout_pc
     int lds_window = 1;
     int coop = 1;
+    bool solo = false;   // fused iterations run k_rollout_solo (one wave per 64 samples) instead of coop's kernel
     int prio_rotate = 0, cu_count = 256;   // pc_rotate_priority (mppi_rollout_pc.h)
     double inj_absmax[CCV_MPPI_MAX_UDIM] = {0, 0, 0, 0, 0};   // largest |control| per dimension in the buffer (sampled: clamp bound)
     // timing
@@ -195,6 +197,16 @@ void fill_window(const ccv_mppi_handle* h, Window& W, const double* x0, const do
 // mode: MODE_FUSED / MODE_ROLLOUT / MODE_COST (mppi_rollout_pc.h)
 template <int MODEL>
 void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int mode) {
+    if (h->solo && h->coop && mode == MODE_FUSED) {
+        // one wave per 64 samples (mppi_rollout_solo.h): K provides two or more such waves per SIMD
+        const dim3 sgrid((h->K + kPcSamples - 1) / kPcSamples), sblock(kPcSamples);
+        if (h->ev_kernel_start)
+            hipExtLaunchKernelGGL((k_rollout_solo<MODEL, MODE_FUSED>), sgrid, sblock, 0, h->stream, h->ev_kernel_start,
+                                  h->ev_kernel_stop, 0, A, W);
+        else
+            hipLaunchKernelGGL((k_rollout_solo<MODEL, MODE_FUSED>), sgrid, sblock, 0, h->stream, A, W);
+        return;
+    }
     if constexpr (MODEL != CCV_MPPI_FULL_BODY) {
     if (h->coop == 2) {
         // three-wave kernel (mppi_rollout_r3.h); not built for full body (see ccv_mppi_create)
@@ -226,8 +238,11 @@ void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const 
     // experiment path (CCV_MPPI_KERNEL=v1): plain one-sample-per-lane kernel
     const dim3 grid((h->K + kBlock - 1) / kBlock), block(kBlock);
     if (mode == MODE_FUSED) {
+        // (timed launch: this path is also the fallback for unbounded headings, so the events must exist here too)
+        if (h->ev_kernel_start) (void)hipEventRecord(h->ev_kernel_start, h->stream);
         if (h->lds_window) hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_PHILOX, true>), grid, block, 0, h->stream, A, W);
         else hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_PHILOX, false>), grid, block, 0, h->stream, A, W);
+        if (h->ev_kernel_stop) (void)hipEventRecord(h->ev_kernel_stop, h->stream);
     } else {
         if (h->lds_window) hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_BUFFER, true>), grid, block, 0, h->stream, A, W);
         else hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_BUFFER, false>), grid, block, 0, h->stream, A, W);
@@ -515,6 +530,18 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     if (h->coop && h->cfg.model != CCV_MPPI_FULL_BODY) h->coop = 2;
     if (h->coop && kenv && std::strcmp(kenv, "r3") == 0) h->coop = 2;
     if (h->coop && kenv && std::strcmp(kenv, "pc") == 0) h->coop = 1;
+    // More blocks of 64 samples than the multi-wave kernels can hold at once (4 workgroups per CU): one wave does
+    // everything for its samples (mppi_rollout_solo.h) -- the SIMDs are kept busy by independent waves then, and the
+    // hand-off between the waves of a workgroup is pure loss.  Measured on 256 CUs (kernel us, multi-wave vs one-wave):
+    // diff drive K = 65 536: 45 vs 56; 98 304: 85 vs 80; 131 072: 106 vs 88; 524 288: 348 vs 295; steering 131 072: 135 vs
+    // 117; full body 65 536: 169 vs 192; 98 304: 316 vs 291; 131 072 (C4): 374 vs 335.  CCV_MPPI_KERNEL=solo forces it.
+    {
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        h->solo = h->coop && !kenv && h->nblocks > 4 * cus;
+        if (h->coop && kenv && std::strcmp(kenv, "solo") == 0) h->solo = true;
+    }
     h->prio_rotate = h->coop ? 1 : 0;   // measured: -4 us on the three-wave kernel (C2), -3 % on the two-wave one (C4)
     if (const char* pv = std::getenv("CCV_MPPI_PRIO")) h->prio_rotate = std::strcmp(pv, "0") != 0;
 

@@ -69,6 +69,7 @@ struct PcShared {
     // (mppi_rollout_r3.h); here it stores them to HBM directly
     static constexpr bool kStage = false;
     static constexpr bool kStageNoise = false;   // (with kStage) the fp32 normals are staged instead of the fp64 controls
+    static constexpr int kPBuf = 2;              // buffers of p: the block being produced and the one being consumed
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
     double c[kMaxH + 4];
     double p[2][kTU][2][kPcSamples];                       // (x,y) - pose of the 8 states of a block, double buffered
@@ -147,11 +148,11 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
         constexpr int tt = decltype(TT)::value;
         const int t = t0 + tt;
         if constexpr (SH::kStage) {   // absolute: the store wave writes them out, the distance wave subtracts the pose
-            sh.p[b & 1][tt][0][lane] = S.x;
-            sh.p[b & 1][tt][1][lane] = S.y;
+            sh.p[b & (SH::kPBuf - 1)][tt][0][lane] = S.x;
+            sh.p[b & (SH::kPBuf - 1)][tt][1][lane] = S.y;
         } else {
-            sh.p[b & 1][tt][0][lane] = S.x - A.x0[0];
-            sh.p[b & 1][tt][1][lane] = S.y - A.x0[1];
+            sh.p[b & (SH::kPBuf - 1)][tt][0][lane] = S.x - A.x0[0];
+            sh.p[b & (SH::kPBuf - 1)][tt][1][lane] = S.y - A.x0[1];
         }
         if (FULL || t < H) {
             if constexpr (MODE != MODE_COST && !SH::kStage) {
@@ -513,11 +514,11 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
         xv[tt] = x;
         yv[tt] = y;
         if constexpr (SH::kStage) {
-            sh.p[b & 1][tt][0][lane] = x;
-            sh.p[b & 1][tt][1][lane] = y;
+            sh.p[b & (SH::kPBuf - 1)][tt][0][lane] = x;
+            sh.p[b & (SH::kPBuf - 1)][tt][1][lane] = y;
         } else {
-            sh.p[b & 1][tt][0][lane] = x - A.x0[0];
-            sh.p[b & 1][tt][1][lane] = y - A.x0[1];
+            sh.p[b & (SH::kPBuf - 1)][tt][0][lane] = x - A.x0[0];
+            sh.p[b & (SH::kPBuf - 1)][tt][1][lane] = y - A.x0[1];
         }
         x = x + u[tt][0] * cs[tt] * dt;
         y = y + u[tt][0] * sn[tt] * dt;
@@ -557,8 +558,8 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
     double px[NV], py[NV], m[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        px[i] = sh.p[b & 1][i0 + i][0][lane];
-        py[i] = sh.p[b & 1][i0 + i][1][lane];
+        px[i] = sh.p[b & (SH::kPBuf - 1)][i0 + i][0][lane];
+        py[i] = sh.p[b & (SH::kPBuf - 1)][i0 + i][1][lane];
         if constexpr (SH::kStage) {   // staged positions are absolute
             px[i] -= A.x0[0];
             py[i] -= A.x0[1];

@@ -226,6 +226,35 @@ def test_two_wave_and_three_wave_kernels_agree(monkeypatch, K, H):
     np.testing.assert_allclose(res[0], res[2], rtol=1e-11, atol=1e-15)
 
 
+@pytest.mark.parametrize("wl,K,H", [("C4", 256, 80), ("C4", 1000, 80), ("C4", 130, 9), ("C4", 64, 3), ("C4", 2049, 128),
+                                    ("C2", 1000, 50), ("C3", 321, 50)])
+def test_one_wave_kernel_agrees_with_the_multi_wave_kernels(monkeypatch, wl, K, H):
+    """Full body with two or more blocks of 64 samples per SIMD runs k_rollout_solo (one wave per 64 samples, no barrier
+    in the time loop, mppi_rollout_solo.h).  Same building blocks as the two- / three-wave kernels: same samples and
+    states bit for bit, costs and controls equal up to the order in which the cost terms are added; and equal to the
+    oracle within the north_star tolerance."""
+    w = configs.workload(wl)
+    p = w.params.with_(num_samples=K, horizon=H)
+    path = helpers.oracle_path(w.path)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    monkeypatch.delenv("CCV_MPPI_KERNEL", raising=False)
+    a = MPPIController(p)
+    monkeypatch.setenv("CCV_MPPI_KERNEL", "solo")
+    b = MPPIController(p)
+    for it in range(2):   # (the second iteration starts from the first one's update)
+        ua = a.iterate(state, p.dt, xr, yr, yaw[0], 11, it, want_stats=False)
+        ub = b.iterate(state, p.dt, xr, yr, yaw[0], 11, it, want_stats=False)
+        np.testing.assert_allclose(ua, ub, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(a.read_controls(), b.read_controls(), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(a.read_candidates(), b.read_candidates(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(a.read_costs(), b.read_costs(), rtol=1e-12)
+    o = helpers.oracle_for(p)
+    for it in range(2):
+        uo = o.iterate(state, p.dt, xr, yr, yaw[0], seed=11, rng="philox", iteration=it)
+    np.testing.assert_allclose(ub, uo, rtol=TOL_U, atol=1e-12)
+
+
 # --------------------------------------------------------------------------------------------------------------
 # edge cases
 # --------------------------------------------------------------------------------------------------------------
