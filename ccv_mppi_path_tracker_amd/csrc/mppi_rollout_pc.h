@@ -70,6 +70,7 @@ struct PcShared {
     static constexpr bool kStage = false;
     static constexpr bool kStageNoise = false;   // (with kStage) the fp32 normals are staged instead of the fp64 controls
     static constexpr int kPBuf = 2;              // buffers of p: the block being produced and the one being consumed
+    static constexpr bool kPruneAlways = false;  // window pruning for every model (pc_consume)
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
     double c[kMaxH + 4];
     double p[2][kTU][2][kPcSamples];                       // (x,y) - pose of the 8 states of a block, double buffered
@@ -601,12 +602,13 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
     // anything unordered (NaN / infinite positions) keeps the point.  On the launch workloads 58-72 % of the iterations
     // remain (diff drive), 38-49 % (full body).  Measured (same box, kernel us): diff drive 50.7 -> 46.7; steering
     // 60.4 -> 63.1 and full body 402 -> 401 (357 -> 357 with pc_noise_ahead), where the producer, not this loop, is the
-    // workgroup's critical chain and the ~200 extra instructions only add contention -- compiled in for diff drive only.
+    // workgroup's critical chain and the ~200 extra instructions only add contention -- compiled in for diff drive only,
+    // and for every model in the one-wave kernel (SH::kPruneAlways), which has no critical chain: every instruction counts.
     // The test costs ~600 cycles per block; the samples of a wave fan out with time, so once a block keeps more than 3/4 of
     // the window the later ones will too and the wave stops testing (*prune_on = 0) for the rest of the launch.
     int jb = 0, je = H4;
 #if !defined(CCV_EXP_NO_PRUNE)
-    if (MODEL == CCV_MPPI_DIFF_DRIVE && (prune_on == nullptr || *prune_on)) {
+    if ((MODEL == CCV_MPPI_DIFF_DRIVE || SH::kPruneAlways) && (prune_on == nullptr || *prune_on)) {
         double xlo = px[0], xhi = px[0], ylo = py[0], yhi = py[0];
 #pragma unroll
         for (int i = 1; i < NV; ++i) {
