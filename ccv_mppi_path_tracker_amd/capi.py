@@ -84,6 +84,7 @@ SIGNATURES = {
     "ccv_mppi_resident_set_pose": (C.c_int, [_H, _dp]),
     "ccv_mppi_resident_step_enqueue": (C.c_int, [_H, C.c_double, C.c_uint64, C.c_uint64, C.c_int32]),
     "ccv_mppi_resident_step_partials_enqueue": (C.c_int, [_H, C.c_double, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p]),
+    "ccv_mppi_resident_step_exchange_enqueue": (C.c_int, [_H, C.c_double, C.c_uint64, C.c_uint64, C.c_int32]),
     "ccv_mppi_resident_read": (C.c_int, [_H, _dp, C.POINTER(C.c_int32), _dp, _dp, _dp, C.POINTER(C.c_int64)]),
     "ccv_mppi_resident_read_trace": (C.c_int, [_H, C.c_int32, _dp, C.POINTER(C.c_int32)]),
     "ccv_mppi_timing_enable": (C.c_int, [_H, C.c_int32]),

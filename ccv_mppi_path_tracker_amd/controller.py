@@ -214,6 +214,10 @@ class MPPIController:
         self._check(self.lib.ccv_mppi_resident_step_partials_enqueue(self._h, float(dt), int(seed), int(iteration),
                                                                      1 if advance else 0, C.c_void_p(dev_ptr)))
 
+    def resident_step_exchange_enqueue(self, dt, seed, iteration, advance=True):
+        self._check(self.lib.ccv_mppi_resident_step_exchange_enqueue(self._h, float(dt), int(seed), int(iteration),
+                                                                     1 if advance else 0))
+
     def resident_read(self):
         """(state, current_index, x_ref, y_ref, yaw_ref0, steps) of the last tick; synchronises."""
         st = np.zeros(5)

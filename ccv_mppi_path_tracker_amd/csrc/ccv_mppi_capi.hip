@@ -818,7 +818,8 @@ int ccv_mppi_resident_set_pose(ccv_mppi_handle* h, const double* state) {
 }
 
 namespace {
-int resident_step(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance, bool normalise, double* vec_out) {
+int resident_step(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance, bool normalise, double* vec_out,
+                  bool exchange = false) {
     if (!h) return CCV_MPPI_ERR_INVALID_ARG;
     if (!(dt == dt)) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "dt is NaN");
     if (!h->d_frame || !h->have_pose) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_resident_set_path and _set_pose first");
@@ -851,7 +852,7 @@ int resident_step(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, i
     HIP_TRY(h, hipGetLastError());
     h->res_steps += 1;
     const double bounds[5] = {0.0, 0.0, h->res_angle_abs[0], h->res_angle_abs[1], h->res_angle_abs[2]};
-    return enqueue_iteration(h, bounds, dt, nullptr, nullptr, 0.0, seed, iter, normalise, vec_out, true);
+    return enqueue_iteration(h, bounds, dt, nullptr, nullptr, 0.0, seed, iter, normalise, vec_out, true, exchange);
 }
 }  // namespace
 
@@ -866,6 +867,12 @@ int ccv_mppi_resident_step_partials_enqueue(ccv_mppi_handle* h, double dt, uint6
     if (h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT)
         return fail(h, CCV_MPPI_ERR_INVALID_ARG, "MIN_SHIFT needs a cross-device min; not supported with partials");
     return resident_step(h, dt, seed, iter, advance, false, dev_partials);
+}
+
+int ccv_mppi_resident_step_exchange_enqueue(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (!h->xchg_connected) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_exchange_create / _connect first");
+    return resident_step(h, dt, seed, iter, advance, false, nullptr, true);
 }
 
 int ccv_mppi_resident_read(ccv_mppi_handle* h, double* state, int32_t* current_index, double* x_ref, double* y_ref,

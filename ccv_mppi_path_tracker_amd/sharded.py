@@ -44,6 +44,8 @@ class ShardedMPPI:
         """The device-resident closed loop, K sharded: every rank holds the same path and pose (backend.resident_setup),
         advances the pose with the same u* and builds the same window; only the partial vector crosses the links.
         backend.local_partials_resident(dt, seed, iteration, advance) -> tensor as local_partials."""
+        if hasattr(self.backend, "iterate_resident"):   # ExchangeBackend
+            return self.backend.iterate_resident(dt, seed, iteration, advance)
         part = self.backend.local_partials_resident(dt, seed, iteration, advance)
         if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
             self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -115,6 +117,13 @@ class ExchangeBackend:
 
     def iterate(self, x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration):
         self.ctl.iterate_exchange_enqueue(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration)
+
+    def resident_setup(self, path_x, path_y, state, resolution=None):
+        self.ctl.resident_set_path(path_x, path_y, resolution)
+        self.ctl.resident_set_pose(state)
+
+    def iterate_resident(self, dt, seed, iteration, advance=True):
+        self.ctl.resident_step_exchange_enqueue(dt, seed, iteration, advance)
 
 
 def combine_partials(parts):

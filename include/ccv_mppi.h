@@ -188,6 +188,8 @@ int ccv_mppi_resident_step_enqueue(ccv_mppi_handle* h, double dt, uint64_t seed,
 /* K sharded over devices: as ccv_mppi_iterate_partials_enqueue; every device advances the same pose with the same u* */
 int ccv_mppi_resident_step_partials_enqueue(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance,
                                             double* dev_partials);
+/* ... or as ccv_mppi_iterate_exchange_enqueue (direct exchange between the devices of one node) */
+int ccv_mppi_resident_step_exchange_enqueue(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance);
 /* Synchronises; any output pointer may be NULL.  x_ref / y_ref: H values, the window of the last step. */
 int ccv_mppi_resident_read(ccv_mppi_handle* h, double* state, int32_t* current_index, double* x_ref, double* y_ref,
                            double* yaw_ref0, int64_t* steps);

@@ -179,6 +179,27 @@ def test_resident_sharded_driver_two_shards_one_device():
         np.testing.assert_allclose(h.ctl.get_nominal(), whole.get_nominal(), rtol=1e-9, atol=1e-12)
 
 
+def test_resident_loop_with_direct_exchange_single_rank():
+    """The resident loop through ExchangeBackend (world = 1: the box is this device's own) follows the plain resident loop."""
+    from ccv_mppi_path_tracker_amd import sharded
+    w = configs.workload("C2", num_samples=2048)
+    p = w.params
+    px, py = amd.make_path(w.path)
+    s0 = start(p, px, py)
+    a, b = MPPIController(p), MPPIController(p)
+    a.resident_set_path(px, py)
+    a.resident_set_pose(s0)
+    xb = sharded.ExchangeBackend(b)
+    assert xb.ok
+    xb.resident_setup(px, py, s0)
+    drv = sharded.ShardedMPPI(xb)
+    for it in range(8):
+        a.resident_step_enqueue(p.dt, 4, it, advance=it > 0)
+        drv.iterate_resident(p.dt, 4, it, advance=it > 0)
+    np.testing.assert_array_equal(a.resident_read()[0], b.resident_read()[0])
+    np.testing.assert_array_equal(a.get_nominal(), b.get_nominal())
+
+
 def test_resident_errors():
     p = configs.diff_drive_defaults(256, 30)
     g = MPPIController(p)
