@@ -278,6 +278,12 @@ bool fast_trig_safe(const ccv_mppi_handle* h, const RolloutArgs& A, int mode) {
     }
     // diff drive advances (sin, cos) of the heading by the step's turn angle: needs |w| dt <= pi/4 (fast_trig.h)
     if (h->cfg.model == CCV_MPPI_DIFF_DRIVE && !(umax[1] * std::fabs(A.dt) <= kSmallTurnLimit)) return false;
+    // full body: the same for yaw, roll and pitch, and the direction angle itself is evaluated without range reduction
+    if (h->cfg.model == CCV_MPPI_FULL_BODY) {
+        if (!(umax[1] * std::fabs(A.dt) <= kSmallTurnLimit) || !(umax[3] * std::fabs(A.dt) <= kSmallTurnLimit) ||
+            !(umax[4] * std::fabs(A.dt) <= kSmallTurnLimit) || !(umax[2] <= kSmallTurnLimit))
+            return false;
+    }
     return bound <= kFastTrigLimit;   // false for NaN
 }
 

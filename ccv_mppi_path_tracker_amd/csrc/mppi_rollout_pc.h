@@ -420,6 +420,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
     CCV_STAMP_AT(ST, 1);
     // ---- 3. sin/cos of the 8 headings
     double sn[kTU], cs[kTU];
+    double fb_sd[FB ? kTU : 1], fb_cd[FB ? kTU : 1], fb_sr[FB ? kTU : 1], fb_cr[FB ? kTU : 1], fb_cp[FB ? kTU : 1];   // full body: direction, roll, pitch
 #if defined(CCV_ABL_NO_SINCOS)
 #pragma unroll
     for (int tt = 0; tt < kTU; ++tt) { sn[tt] = hd[tt] * 0.5; cs[tt] = 1.0 - hd[tt] * 0.25; }
@@ -445,6 +446,60 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
         }
         S.sn = s_;
         S.cs = c_;
+    } else if constexpr (FB) {
+        // full body needs sin / cos of four angles per step: heading = yaw + direction, direction, roll, pitch.  Every one
+        // of them either is small (|direction| <= pi/4: a clamped control) or changes by a small step (yaw, roll, pitch:
+        // rate * dt; the host admits this kernel only for |rate| dt <= pi/4, fast_trig_safe()), so per block one full
+        // evaluation of sin / cos(yaw), (roll), (pitch) at the block's first step is advanced by rotations, and the short
+        // polynomials (no range reduction, no quadrant logic) do the rest: 32 batched short evaluations + 3 full ones per
+        // block instead of 32 full ones.  sin / cos(yaw + direction) comes from the addition theorem.  Rounding differs
+        // from the direct evaluation by a few ulp per step; the chains restart from the accumulated angles every block.
+        double turn[kTU], st_[kTU], ct_[kTU], dir[kTU];
+#pragma unroll
+        for (int tt = 0; tt < kTU; ++tt) {
+            turn[tt] = u[tt][1] * dt;
+            dir[tt] = u[tt][2];
+        }
+        kernel_sincos_n<kTU>(turn, st_, ct_);
+        kernel_sincos_n<kTU>(dir, fb_sd, fb_cd);
+        double sy, cy;
+        fast_sincos(yawv[0], sy, cy);
+#pragma unroll
+        for (int tt = 0; tt < kTU; ++tt) {
+            sn[tt] = fma(sy, fb_cd[tt], cy * fb_sd[tt]);
+            cs[tt] = fma(cy, fb_cd[tt], -(sy * fb_sd[tt]));
+            const double s2 = fma(sy, ct_[tt], cy * st_[tt]);
+            const double c2 = fma(cy, ct_[tt], -(sy * st_[tt]));
+            sy = s2;
+            cy = c2;
+        }
+        if constexpr (COST) {
+            double rinc[kTU], pinc[kTU], sri[kTU], cri[kTU], spi[kTU], cpi[kTU];
+#pragma unroll
+            for (int tt = 0; tt < kTU; ++tt) {
+                rinc[tt] = u[tt][3] * dt;
+                pinc[tt] = u[tt][4] * dt;
+            }
+            kernel_sincos_n<kTU>(rinc, sri, cri);
+            kernel_sincos_n<kTU>(pinc, spi, cpi);
+            double sr, cr, sp, cp;
+            fast_sincos(rollv[0], sr, cr);
+            fast_sincos(pitchv[0], sp, cp);
+#pragma unroll
+            for (int tt = 0; tt < kTU; ++tt) {
+                fb_sr[tt] = sr;
+                fb_cr[tt] = cr;
+                fb_cp[tt] = cp;
+                const double s2 = fma(sr, cri[tt], cr * sri[tt]);
+                const double c2 = fma(cr, cri[tt], -(sr * sri[tt]));
+                sr = s2;
+                cr = c2;
+                const double s3 = fma(sp, cpi[tt], cp * spi[tt]);
+                const double c3 = fma(cp, cpi[tt], -(sp * spi[tt]));
+                sp = s3;
+                cp = c3;
+            }
+        }
     } else {
         // independent chains, evaluated stage by stage in two groups of four
         constexpr int SG = 4;
@@ -493,14 +548,10 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
                     cost += in ? cz : 0.0;
                     cost += in ? cr : 0.0;
                 }
-                double sd_, cd_, sr_, cr_, sp_, cp_;
-                fast_sincos(u[tt][2], sd_, cd_);
-                fast_sincos(rollv[tt], sr_, cr_);
-                fast_sincos(pitchv[tt], sp_, cp_);
-                S.p_sdir = sd_;
-                S.p_cdir = cd_;
-                S.p_c2 = -A.fb_L * sr_;             // CoM.y (fb:482)
-                S.p_c3 = A.fb_L * cp_ * cr_;        // CoM.z
+                S.p_sdir = fb_sd[tt];
+                S.p_cdir = fb_cd[tt];
+                S.p_c2 = -A.fb_L * fb_sr[tt];                 // CoM.y (fb:482)
+                S.p_c3 = A.fb_L * fb_cp[tt] * fb_cr[tt];      // CoM.z
                 S.p_ac = u[tt][0] * u[tt][1];       // fb:471
                 S.p_v = u[tt][0];
                 S.p_rv = u[tt][3];

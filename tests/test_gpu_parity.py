@@ -386,6 +386,38 @@ def test_diff_drive_turn_per_step_gate(dt):
     np.testing.assert_allclose(g.read_candidates(), xs_o, rtol=1e-11, atol=1e-11)
 
 
+@pytest.mark.parametrize("case", ["launch", "dt_0.7", "dt_1.0", "wide_direction", "fast_roll"])
+def test_full_body_small_angle_gates(case):
+    """Full body evaluates sin / cos of yaw, roll and pitch once per block of 8 steps and advances them by rotations with
+    short polynomials, and takes sin / cos of the direction angle without range reduction (pc_produce_batched): valid for
+    |rate| dt <= pi/4 and |direction| <= pi/4, which the host checks per call (fast_trig_safe) -- anything else runs the plain
+    kernel.  Either way the oracle's direct evaluations are matched within the usual tolerances."""
+    p = configs.workload("C4", num_samples=320, horizon=40).params
+    if case == "dt_0.7":        # w_max = 1 rad/s: 0.7 rad per step stays inside the gate, 1.0 below does not
+        p = p.with_(dt=0.7)
+    elif case == "dt_1.0":
+        p = p.with_(dt=1.0)
+    elif case == "wide_direction":   # direction up to 60 degrees
+        lo, hi = list(p.u_min), list(p.u_max)
+        lo[2], hi[2] = -np.pi / 3, np.pi / 3
+        p = p.with_(u_min=tuple(lo), u_max=tuple(hi))
+    elif case == "fast_roll":        # roll rate up to 10 rad/s: 1 rad per step
+        lo, hi = list(p.u_min), list(p.u_max)
+        lo[3], hi[3] = -10.0, 10.0
+        p = p.with_(u_min=tuple(lo), u_max=tuple(hi))
+    path = helpers.oracle_path("dkan")
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    o, g = helpers.oracle_for(p), MPPIController(p)
+    for it in range(2):
+        u_o = o.iterate(state, p.dt, xr, yr, yaw[0], seed=8, rng="philox", iteration=it)
+        u_g, st = g.iterate(state, p.dt, xr, yr, yaw[0], 8, it)
+    assert np.max(np.abs(g.read_costs() - o.costs()) / o.costs()) < TOL_COST
+    assert helpers.rel_err(u_g, u_o) < 1e-8
+    xs_o = np.stack([o.states("x"), o.states("y")], axis=-1)
+    np.testing.assert_allclose(g.read_candidates(), xs_o, rtol=1e-10, atol=1e-10)
+
+
 @pytest.mark.parametrize("kind", ["random", "circle", "duplicates", "far", "line_behind"])
 def test_window_pruning_is_exact_on_awkward_windows(kind):
     """Diff drive skips window points that cannot be the nearest one for any sample of a wave (pc_consume: bounds of the
