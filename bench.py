@@ -52,6 +52,23 @@ def rollout_kernel_name(model, k_local, device):
     return "k_rollout_pc" if model == "full_body" else "k_rollout_r3"
 
 
+def device_copy_gbs(torch, nbytes=1 << 30, reps=10):
+    """Achievable HBM ceiling next to the nominal 8 TB/s: a device-to-device copy of 1 GiB, bytes read +
+    bytes written per second, best of `reps` (torch's copy kernel; measured after the timed region)."""
+    a = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda")
+    b = torch.ones(nbytes // 8, dtype=torch.float64, device="cuda")
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        a.copy_(b)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
 def script_inputs(amd, w, n):
     """n (pose, window) pairs along the reference path: the robot advances ~v_ref*dt per step with a small lateral
     and heading offset, as a tracking controller would see them."""
@@ -325,6 +342,8 @@ def main():
                          "iteration_achieved": (B * k_local / iter_avg_s / 1e9) if iter_avg_s > 0 else None,
                          "iteration_frac": (B * k_local / iter_avg_s / 1e9 / HBM_PEAK_GBS) if iter_avg_s > 0 else None},
         }
+        if world == 1:
+            out["roofline"]["device_copy_gbs"] = device_copy_gbs(torch)
         if args.closed_loop:
             tr = ctl.resident_read_trace()
             d = np.hypot(cl_px[None, :] - tr[:, 0:1], cl_py[None, :] - tr[:, 1:2]).min(axis=1)
