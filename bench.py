@@ -111,6 +111,40 @@ def cpu_baseline(w, budget_s=12.0):
             "host_cpus": os.cpu_count()}
 
 
+def cpu_baseline_threads(w, threads, budget_s=6.0):
+    """The strong CPU baseline of SURVEY.md 8(d): the same oracle in its counter-based (Philox) mode, K sharded over
+    `threads` host threads exactly as it is over GPUs (global sample ids, [sum w, sum w*u] combined, then divided); the
+    C++ calls release the GIL.  Whole iterations until ~budget_s."""
+    import concurrent.futures as cf
+    import ccv_mppi_path_tracker_amd as amd
+    from oracle import oracle_lib as O
+    p = w.params
+    k_t = p.num_samples // threads
+    shards = [O.Oracle(p.model, k_t, p.horizon, p.control_noise, p.lam, p.v_ref, p.u_min, p.u_max,
+                       path_weight=p.path_weight, v_weight=p.v_weight, zmp_weight=p.zmp_weight,
+                       roll_v_weight=p.roll_v_weight, back_weight=p.back_weight, yaw_weight=p.yaw_weight,
+                       roll_off=p.roll_off, steer_off=p.steer_off) for _ in range(threads)]
+    inputs = script_inputs(amd, w, 16)
+    n, t0 = 0, time.perf_counter()
+    with cf.ThreadPoolExecutor(threads) as pool:
+        while True:
+            s, xr, yr, yaw0 = inputs[n % len(inputs)]
+            us = list(pool.map(lambda a: a[1].iterate(s, p.dt, xr, yr, yaw0, seed=42, rng="philox", iteration=n, k_offset=a[0] * k_t),
+                               enumerate(shards)))
+            sw = np.array([o.sum_w() for o in shards])
+            u = np.tensordot(sw, np.stack(us), axes=1) / sw.sum()
+            for o in shards:
+                o.set_nominal(u)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= 256:
+                break
+    return {"value": k_t * threads * n / el, "unit": "rollouts/s", "cores": threads, "kind": "port",
+            "sample": "%d whole iterations of %s, K sharded over %d threads (oracle/mppi_oracle.cpp, Philox mode, "
+                      "%.1f s, %.1f ms/iteration)" % (n, w.description, threads, el, 1e3 * el / n),
+            "host_cpus": os.cpu_count()}
+
+
 def latest_pmc_traffic(workload_name):
     """HBM bytes per rollout-kernel launch from the committed rocprofv3 --pmc summary (profiles/*pmc*.json)."""
     best = None
@@ -351,6 +385,8 @@ def main():
                                   "path_error_rms_m": float(np.sqrt(np.mean(d * d))), "path_error_max_m": float(d.max())}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
+            # (the GPU boxes give a one-GPU job 16 host CPUs)
+            out["cpu_baseline_all_cores"] = cpu_baseline_threads(w, max(1, min(16, os.cpu_count() or 1)))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
