@@ -378,6 +378,26 @@ def main():
         }
         if world == 1:
             out["roofline"]["device_copy_gbs"] = device_copy_gbs(torch)
+            if not args.closed_loop:
+                # SURVEY.md 8(d), end to end through the blocking C-ABI call: host window in, u* out (PCIe and the host
+                # synchronisation included), closed loop on the host plant.  Never `value`.
+                px_e, py_e = amd.make_path(w.path)
+                s_e = np.zeros(p.nstate)
+                s_e[0], s_e[1] = px_e[0], py_e[0]
+                ctl.set_nominal(np.zeros((p.horizon - 1, p.udim)))
+                lat = []
+                for i in range(220):
+                    t_e = time.perf_counter()
+                    _, xr_e, yr_e, yaw_e = amd.calc_ref_path(px_e, py_e, s_e[0], s_e[1], p.v_ref, p.dt, p.resolution, p.horizon)
+                    u_e = ctl.iterate(s_e, p.dt, xr_e, yr_e, yaw_e[0], seed, i, want_stats=False)
+                    lat.append(time.perf_counter() - t_e)
+                    s_e = amd.plant_step(p.model, s_e, u_e[0], p.dt)
+                    if np.hypot(px_e[-1] - s_e[0], py_e[-1] - s_e[1]) < 1.0:   # end of the course: start over
+                        s_e = np.zeros(p.nstate)
+                        s_e[0], s_e[1] = px_e[0], py_e[0]
+                out["end_to_end"] = {"blocking_iterate_us_median": 1e6 * float(np.median(lat[20:])),
+                                     "what": "ccv_mppi_calc_ref_path + blocking ccv_mppi_iterate per tick (H2D window, D2H u*, "
+                                             "stream sync), closed loop on the host plant, 200 ticks after 20"}
         if args.closed_loop:
             tr = ctl.resident_read_trace()
             d = np.hypot(cl_px[None, :] - tr[:, 0:1], cl_py[None, :] - tr[:, 1:2]).min(axis=1)
