@@ -32,8 +32,8 @@ struct AdvanceArgs {
 constexpr int kAdvanceThreads = 1024;   // one workgroup; a path of a few thousand poses is one or two batches of loads per thread
 
 __global__ __launch_bounds__(kAdvanceThreads) void k_advance(const AdvanceArgs A) {
-    __shared__ double s_d[kAdvanceThreads];
-    __shared__ int s_i[kAdvanceThreads];
+    __shared__ double s_d[kAdvanceThreads / 64];
+    __shared__ int s_i[kAdvanceThreads / 64];
     __shared__ int s_start;
     ResidentFrame& F = *A.frame;
     // ---- pose (every thread computes it: wave-uniform, no hand-off)
@@ -74,24 +74,32 @@ __global__ __launch_bounds__(kAdvanceThreads) void k_advance(const AdvanceArgs A
             }
         }
     }
-    s_d[threadIdx.x] = best_d;
-    s_i[threadIdx.x] = best_i;
-    __syncthreads();   // (also: every thread has read the old pose)
-    for (int half = kAdvanceThreads / 2; half > 0; half >>= 1) {
-        if ((int)threadIdx.x < half) {
-            const double od = s_d[threadIdx.x + half];
-            const int oi = s_i[threadIdx.x + half];
-            const double md = s_d[threadIdx.x];
-            const int mi = s_i[threadIdx.x];
-            const bool take = oi >= 0 && (mi < 0 || od < md || (od == md && oi < mi));
-            if (take) {
-                s_d[threadIdx.x] = od;
-                s_i[threadIdx.x] = oi;
-            }
-        }
-        __syncthreads();
+    // (distance, index) minimum, lexicographic: the smallest distance, and among equal distances the smallest index --
+    // what the serial scan's strict '<' keeps.  Two wave reductions per level (DPP), one LDS hand-off between the levels.
+    auto lexmin = [](double d, int i, double& d_out, int& i_out) {
+        const double dm = wave_min(d);                                   // (no candidate: d = 100, the gate)
+        const double im = wave_min((i >= 0 && d == dm) ? (double)i : 1.0e300);
+        d_out = dm;
+        i_out = im < 1.0e299 ? (int)im : -1;
+    };
+    double wd;
+    int wi;
+    lexmin(best_d, best_i, wd, wi);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        s_d[wave] = wd;
+        s_i[wave] = wi;
     }
-    if (threadIdx.x == 0) s_start = s_i[0] < 0 ? 0 : s_i[0];
+    __syncthreads();   // (also: every thread has read the old pose)
+    if (wave == 0) {
+        constexpr int NW = kAdvanceThreads / 64;
+        const double d2 = lane < NW ? s_d[lane] : 100.0;
+        const int i2 = lane < NW ? s_i[lane] : -1;
+        double fd;
+        int fi;
+        lexmin(d2, i2, fd, fi);
+        if (lane == 0) s_start = fi < 0 ? 0 : fi;
+    }
     __syncthreads();
     const int start = s_start;
     // ---- calc_RefPath(): the index is the truncation of a double; past the end the final pose repeats
