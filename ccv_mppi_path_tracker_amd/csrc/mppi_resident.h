@@ -2,7 +2,7 @@
 // iterations need nothing from the host but their launches.
 //
 //   k_advance   (optional) the commanded motion u*[0] applied to the pose for one period -- the kinematic plant of the
-//               closed-loop harness, the Euler model of predict_NextState() (dd:103-110, sd:119-126, fb:445-463 pose part)
+//               closed-loop harness, the Euler model of predict_NextState() (dd:104-109, sd:120-125, fb:445-452 pose part)
 //               get_CurrentIndex()   nearest path pose inside the 100 m gate      dd:126-140  sd:142-156  fb:335-349
 //               calc_RefPath()       window of H poses, stride v_ref*dt/resolution dd:156-181  sd:172-197  fb:365-392
 //               + the distance coefficients of the window relative to the pose (fill_window() in ccv_mppi_capi.hip)

@@ -172,7 +172,7 @@ int ccv_mppi_iterate_exchange_enqueue(ccv_mppi_handle* h, const double* x0, doub
 /* ---- device-resident closed loop -------------------------------------------------- */
 /* The per-tick prologue of run() on the device: the whole reference path and the pose live in HBM, and every step does
  *   (advance != 0) pose <- pose advanced for dt by the command u*[0] of the previous step (the Euler model of
- *                  predict_NextState(), dd:103-110 / sd:119-126 / fb:445-463: the closed-loop plant, what the robot does
+ *                  predict_NextState(), dd:104-109 / sd:120-125 / fb:445-452: the closed-loop plant, what the robot does
  *                  between two ticks; ccv_mppi_plant_step() in ccv_mppi_host.h is the same arithmetic on the host)
  *   get_CurrentIndex() (dd:126-140) + calc_RefPath() (dd:156-181) from that pose, then the iteration itself
  * with no host data in between: a closed loop costs three kernel launches per tick and no PCIe traffic.  Window, index
