@@ -76,6 +76,7 @@ struct RolloutArgs {
     double* statpart;   // [nparts][3]: min cost, max cost, zero-weight count
     int32_t nparts, fuse_update;
     int32_t prio_rotate, cu_count;   // k_rollout_pc / k_rollout_r3: see pc_rotate_priority()
+    int32_t prune, reserved0;        // exact pruning of the window in the distance loop (pc_prune_window); 0 = off
     // deferred ccv_mppi_apply_partials_enqueue (K sharded over devices): when set, the warm start is pending_vec[1..] /
     // pending_vec[0]; every workgroup forms it while staging u* in LDS and workgroup 0 writes it (and sum w) back
     const double* pending_vec;
@@ -394,6 +395,35 @@ CCV_WAVE_REDUCE(wave_sum, op_add)
 CCV_WAVE_REDUCE(wave_min, op_min)
 CCV_WAVE_REDUCE(wave_max, op_max)
 #undef CCV_WAVE_REDUCE
+
+// Four 64-lane fp32 reductions at once, each one DPP-modified VALU instruction per step (the compiler does not fold a DPP
+// move into v_min / v_max and puts a canonicalising v_max in front of every fminf): 24 instructions + 4 v_readlane for
+// four results, against ~25 per fp64 reduction above.  The four chains are interleaved, so a step's DPP read of a register
+// is four instructions behind its write (the DPP hazard needs two wait states; the leading s_nop covers the producer of
+// the inputs, which the compiler's hazard recogniser cannot see into from outside the asm).  row_bcast:15 / :31 carry a
+// row's result into the next row(s); lane 63 ends with the result of all 64 lanes.  NaN operands are ignored (IEEE
+// minNum / maxNum); all 64 lanes must be active.
+#define CCV_RED4_STEP(O0, O1, O2, O3, CTRL)                                                           \
+    O0 " %0, %0, %0 " CTRL "\n\t" O1 " %1, %1, %1 " CTRL "\n\t" O2 " %2, %2, %2 " CTRL "\n\t" O3 " %3, %3, %3 " CTRL "\n\t"
+#define CCV_RED4(NAME, O0, O1, O2, O3)                                                                \
+    __device__ __forceinline__ void NAME(float& a, float& b, float& c, float& d) {                    \
+        asm volatile("s_nop 1\n\t"                                                                    \
+                     CCV_RED4_STEP(O0, O1, O2, O3, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")  \
+                     CCV_RED4_STEP(O0, O1, O2, O3, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")  \
+                     CCV_RED4_STEP(O0, O1, O2, O3, "row_half_mirror row_mask:0xf bank_mask:0xf")      \
+                     CCV_RED4_STEP(O0, O1, O2, O3, "row_mirror row_mask:0xf bank_mask:0xf")           \
+                     CCV_RED4_STEP(O0, O1, O2, O3, "row_bcast:15 row_mask:0xa bank_mask:0xf")         \
+                     CCV_RED4_STEP(O0, O1, O2, O3, "row_bcast:31 row_mask:0xc bank_mask:0xf")         \
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d));                                           \
+        a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));                         \
+        b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));                         \
+        c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));                         \
+        d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 63));                         \
+    }
+CCV_RED4(wave_min_max_min_max_f32, "v_min_f32_dpp", "v_max_f32_dpp", "v_min_f32_dpp", "v_max_f32_dpp")
+CCV_RED4(wave_min4_f32, "v_min_f32_dpp", "v_min_f32_dpp", "v_min_f32_dpp", "v_min_f32_dpp")
+#undef CCV_RED4
+#undef CCV_RED4_STEP
 
 struct UpdateArgs {
     const double* u;

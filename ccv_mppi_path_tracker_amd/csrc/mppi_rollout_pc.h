@@ -70,7 +70,6 @@ struct PcShared {
     static constexpr bool kStage = false;
     static constexpr bool kStageNoise = false;   // (with kStage) the fp32 normals are staged instead of the fp64 controls
     static constexpr int kPBuf = 2;              // buffers of p: the block being produced and the one being consumed
-    static constexpr bool kPruneAlways = false;  // window pruning for every model (pc_consume)
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
     double c[kMaxH + 4];
     double p[2][kTU][2][kPcSamples];                       // (x,y) - pose of the 8 states of a block, double buffered
@@ -598,6 +597,111 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Exact pruning of the window for one wave and one block of states.  f_j(p) = a_j px + b_j py + c_j (= |p - r_j|^2 - |p|^2)
+// is linear in p, so is the difference of two of them: window point j cannot be the nearest one for ANY position p of the
+// wave if some other point r DOMINATES it over a set that contains them all,
+//     min over the box B of (f_j - f_r)(p)  =  (c_j - c_r) + min((a_j - a_r) x) + min((b_j - b_r) y)  >  0,
+// i.e. B lies strictly on r's side of the bisector of r_j and r.  B is the bounding box of the wave's NV x 64 positions;
+// the candidates r are the window points nearest to B's four corners.  Lanes take the role of window points; the
+// survivors are contiguous along a path, so the distance loop runs over their hull.  On the launch workload 31 % of the
+// (state, point) pairs remain (tools/prune_study.py; all-pairs dominance over the same boxes: 30 %, the hull of the true
+// nearest points: 24 %), against 56 % for the round-1 test (one bound M = min_j max_B f_j against min_B f_j, which takes
+// the two extrema at different corners).
+// Nothing here assumes a path-like window: any point excluded is excluded by a valid inequality, the rest costs time only.
+// Rounding: the box and the choice of r are made in fp32 (any r is a valid dominator; the box is rounded outwards), the
+// inequality itself in fp64 against T = 1e-9 * (sum of the magnitudes that enter it) -- the rounding errors of the test and
+// of the loop's own f_j(p), f_r(p) are below 1e-15 of that sum.  Everything unordered (NaN / infinite positions or
+// coefficients) fails the comparison and keeps the point; a lane whose own position is not finite ends at the 100 m
+// gate value whatever the loop covers.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NV, int NHALF, class SH>   // NHALF: window points per lane (2 when the window is longer than 64)
+__device__ __forceinline__ void pc_prune_window(const RolloutArgs& A, const SH& sh, const double (&px)[NV], const double (&py)[NV],
+                                                const int lane, int& jb, int& je) {
+    // ---- bounding box of the NV x 64 positions
+    float xlo = (float)px[0], ylo = (float)py[0];
+    float xhi = xlo, yhi = ylo;
+#pragma unroll
+    for (int i = 1; i < NV; ++i) {
+        const float fx = (float)px[i], fy = (float)py[i];
+        xlo = fminf(xlo, fx);
+        xhi = fmaxf(xhi, fx);
+        ylo = fminf(ylo, fy);
+        yhi = fmaxf(yhi, fy);
+    }
+    wave_min_max_min_max_f32(xlo, xhi, ylo, yhi);
+    // outwards: |x - (float)x| <= 2^-24 |x|, or 2^-126 where fp32 goes subnormal / flushes
+    const double bx0 = (double)xlo - (fabs((double)xlo) * 1.2e-7 + 1.0e-37), bx1 = (double)xhi + (fabs((double)xhi) * 1.2e-7 + 1.0e-37);
+    const double by0 = (double)ylo - (fabs((double)ylo) * 1.2e-7 + 1.0e-37), by1 = (double)yhi + (fabs((double)yhi) * 1.2e-7 + 1.0e-37);
+    const double X = fmax(fabs(bx0), fabs(bx1)), Y = fmax(fabs(by0), fabs(by1));
+    // ---- this lane's window points: j = lane, and lane + 64 when the window is longer than 64
+    double2 ab[NHALF];
+    double c[NHALF], tj[NHALF];
+    float v[4][NHALF];
+    bool valid[NHALF];
+#pragma unroll
+    for (int hh = 0; hh < NHALF; ++hh) {
+        const int j = lane + 64 * hh;
+        valid[hh] = j < A.H;
+        ab[hh] = valid[hh] ? sh.ab[j] : make_double2(0.0, 0.0);
+        c[hh] = valid[hh] ? sh.c[j] : INFINITY;
+        tj[hh] = 1.0e-9 * (fabs(c[hh]) + (fabs(ab[hh].x) * X + fabs(ab[hh].y) * Y));
+        // f_j at the four corners, fp32: only to choose the dominators
+        const float a32 = (float)ab[hh].x, b32 = (float)ab[hh].y, c32 = (float)c[hh];
+        v[0][hh] = __builtin_fmaf(a32, xlo, __builtin_fmaf(b32, ylo, c32));
+        v[1][hh] = __builtin_fmaf(a32, xlo, __builtin_fmaf(b32, yhi, c32));
+        v[2][hh] = __builtin_fmaf(a32, xhi, __builtin_fmaf(b32, ylo, c32));
+        v[3][hh] = __builtin_fmaf(a32, xhi, __builtin_fmaf(b32, yhi, c32));
+    }
+    float best[4], mine[4];
+    unsigned long long upper[4];   // lanes whose better candidate is lane + 64
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        upper[k] = 0ull;
+        mine[k] = v[k][0];
+        if constexpr (NHALF == 2) {
+            const bool up = v[k][1] < v[k][0];
+            upper[k] = __ballot(up);
+            mine[k] = up ? v[k][1] : v[k][0];
+        }
+        best[k] = mine[k];
+    }
+    wave_min4_f32(best[0], best[1], best[2], best[3]);
+    int jr[4];
+    bool ok[4];
+    double2 abr[4];
+    double cr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long at = __ballot(mine[k] == best[k]);   // (empty when every value is NaN)
+        ok[k] = at != 0ull;
+        const int r = ok[k] ? __builtin_ctzll(at) : 0;
+        jr[k] = r + (int)((upper[k] >> r) & 1ull) * 64;
+        abr[k] = sh.ab[jr[k]];   // wave-uniform address: broadcast reads, all four in flight together
+        cr[k] = sh.c[jr[k]];
+    }
+    // ---- dominance of this lane's points by each of the four
+    unsigned long long keep[2] = {0ull, 0ull};
+#pragma unroll
+    for (int hh = 0; hh < NHALF; ++hh) {
+        bool kp = valid[hh];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double da = ab[hh].x - abr[k].x, db = ab[hh].y - abr[k].y, dc = c[hh] - cr[k];
+            const double L = dc + (fmin(da * bx0, da * bx1) + fmin(db * by0, db * by1));
+            const double T = tj[hh] + 1.0e-9 * (fabs(cr[k]) + (fabs(abr[k].x) * X + fabs(abr[k].y) * Y));
+            kp = kp && !(ok[k] && L > T);
+        }
+        keep[hh] = __ballot(kp);
+    }
+    if (keep[0] | keep[1]) {
+        const int lo = keep[0] ? __builtin_ctzll(keep[0]) : 64 + __builtin_ctzll(keep[1]);
+        const int hi = keep[1] ? 127 - __builtin_clzll(keep[1]) : 63 - __builtin_clzll(keep[0]);
+        jb = lo & ~3;
+        je = (hi | 3) + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // consumer: min over the H window points of (a_j px + b_j py + c_j) for the NV states of one block, then the path cost.
 // Straight fp64 FMA/MIN; four window points per iteration so the LDS broadcast reads are covered and the compiler's
 // canonicalising max in front of fmin() is paid once per four minima.
@@ -645,67 +749,15 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
             asm("v_min_f64 %0, %1, %2" : "=v"(m[i]) : "v"(m[i]), "v"(t));
         }
     };
-    // ---- exact pruning of the window (wave-uniform): f_j(p) = a_j px + b_j py + c_j is linear in p, so over the bounding
-    // box of this wave's NV x 64 positions it lies in [LB_j, UB_j] with the bounds taken at box corners.  M = min_j UB_j is
-    // an upper bound of min_j f_j(p) for every p in the box, hence a point with LB_j > M cannot be the nearest one for any
-    // of them.  Lanes take the role of window points here; the survivors are contiguous along a path, so the loop runs
-    // over their hull [lo, hi].  The comparison is widened by 1e-9 relative (the loop's own rounding is ~1e-15), and
-    // anything unordered (NaN / infinite positions) keeps the point.  On the launch workloads 58-72 % of the iterations
-    // remain (diff drive), 38-49 % (full body).  Measured (same box, kernel us): diff drive 50.7 -> 46.7; steering
-    // 60.4 -> 63.1 and full body 402 -> 401 (357 -> 357 with pc_noise_ahead), where the producer, not this loop, is the
-    // workgroup's critical chain and the ~200 extra instructions only add contention -- compiled in for diff drive only,
-    // and for every model in the one-wave kernel (SH::kPruneAlways), which has no critical chain: every instruction counts.
-    // The test costs ~600 cycles per block; the samples of a wave fan out with time, so once a block keeps more than 3/4 of
-    // the window the later ones will too and the wave stops testing (*prune_on = 0) for the rest of the launch.
+    // ---- exact pruning of the window (pc_prune_window below): the loop runs over the hull [jb, je) of the window points
+    // that can be the nearest one for some sample of this wave
     int jb = 0, je = H4;
 #if !defined(CCV_EXP_NO_PRUNE)
-    if ((MODEL == CCV_MPPI_DIFF_DRIVE || SH::kPruneAlways) && (prune_on == nullptr || *prune_on)) {
-        double xlo = px[0], xhi = px[0], ylo = py[0], yhi = py[0];
-#pragma unroll
-        for (int i = 1; i < NV; ++i) {
-            xlo = fmin(xlo, px[i]);
-            xhi = fmax(xhi, px[i]);
-            ylo = fmin(ylo, py[i]);
-            yhi = fmax(yhi, py[i]);
-        }
-        xlo = wave_min(xlo);
-        xhi = wave_max(xhi);
-        ylo = wave_min(ylo);
-        yhi = wave_max(yhi);
-        const int nhalf = H4 > 64 ? 2 : 1;
-        double lb[2], ubm = INFINITY;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            lb[hh] = -INFINITY;   // (a point this lane does not hold: never pruned by this lane, never counted)
-            if (hh < nhalf) {
-                const int j = lane + 64 * hh;
-                if (j < H4) {
-                    const double2 ab = sh.ab[j];
-                    const double c = sh.c[j];
-                    const double ax0 = ab.x * xlo, ax1 = ab.x * xhi, by0 = ab.y * ylo, by1 = ab.y * yhi;
-                    lb[hh] = c + (fmin(ax0, ax1) + fmin(by0, by1));
-                    const double ub = c + (fmax(ax0, ax1) + fmax(by0, by1));
-                    ubm = ub == ub ? fmin(ubm, ub) : ubm;   // (a NaN bound does not lower M)
-                }
-            }
-        }
-        const double M = wave_min(ubm);
-        const double slack = 1.0e-9 * (fabs(M) + 1.0);
-        unsigned long long keep[2] = {0ull, 0ull};
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            if (hh < nhalf) {
-                const int j = lane + 64 * hh;
-                const double tol = slack + 1.0e-9 * fabs(lb[hh]);
-                keep[hh] = __ballot(j < A.H && !(lb[hh] > M + tol));   // (j >= H: padding, c = +inf)
-            }
-        }
-        if (keep[0] | keep[1]) {
-            const int lo = keep[0] ? __builtin_ctzll(keep[0]) : 64 + __builtin_ctzll(keep[1]);
-            const int hi = keep[1] ? 127 - __builtin_clzll(keep[1]) : 63 - __builtin_clzll(keep[0]);
-            jb = lo & ~3;
-            je = (hi | 3) + 1;
-        }
+    if (A.prune && (prune_on == nullptr || *prune_on)) {
+        if (H4 > 64) pc_prune_window<NV, 2>(A, sh, px, py, lane, jb, je);
+        else pc_prune_window<NV, 1>(A, sh, px, py, lane, jb, je);
+        // the samples of a wave fan out with time: once a block keeps more than 3/4 of the window the later ones will too,
+        // and the wave stops testing for the rest of the launch
         if (prune_on && 4 * (je - jb) > 3 * H4) *prune_on = 0;
     }
 #endif

@@ -33,7 +33,6 @@ struct R3Shared {
     static constexpr bool kStage = true;
     static constexpr bool kStageNoise = udim_of(MODEL) > 2;
     static constexpr int kPBuf = 2;
-    static constexpr bool kPruneAlways = false;
     // (p, ab, c are contiguous and are reused as the epilogue's transpose buffers)
     double p[2][kTU][2][kPcSamples];                       // absolute (x,y) of the 8 states of a block, double buffered
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points

@@ -19,7 +19,6 @@ struct SoloShared {
     static constexpr bool kStage = false;
     static constexpr bool kStageNoise = false;
     static constexpr int kPBuf = 1;                        // produced and consumed by the same wave, one after the other
-    static constexpr bool kPruneAlways = true;             // no critical chain to protect: every instruction saved counts
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
     double c[kMaxH + 4];
     double p[1][kTU][2][kPcSamples];                       // (x,y) - pose of the 8 states of a block; epilogue: transpose buffer
