@@ -19,6 +19,7 @@ ERR_NO_DEVICE = -2
 ERR_HIP = -3
 ERR_STATE = -4
 ERR_ALLOC = -5
+ERR_TIMEOUT = -6
 
 DIFF_DRIVE, STEERING_DIFF_DRIVE, FULL_BODY = 0, 1, 2
 FLAG_ROLL_OFF, FLAG_STEER_OFF, FLAG_MIN_SHIFT, FLAG_NO_STATE_STORE = 0x1, 0x2, 0x4, 0x8
@@ -79,6 +80,7 @@ SIGNATURES = {
     "ccv_mppi_exchange_handle_bytes": (C.c_int, []),
     "ccv_mppi_exchange_create": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p]),
     "ccv_mppi_exchange_connect": (C.c_int, [_H, C.c_void_p]),
+    "ccv_mppi_exchange_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccv_mppi_iterate_exchange_enqueue": (C.c_int, [_H, _dp, C.c_double, _dp, _dp, C.c_double, C.c_uint64, C.c_uint64]),
     "ccv_mppi_resident_set_path": (C.c_int, [_H, _dp, _dp, C.c_int32, C.c_double]),
     "ccv_mppi_resident_set_pose": (C.c_int, [_H, _dp]),

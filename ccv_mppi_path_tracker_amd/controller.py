@@ -189,6 +189,12 @@ class MPPIController:
         buf = C.create_string_buffer(blob, len(blob))
         self._check(self.lib.ccv_mppi_exchange_connect(self._h, C.cast(buf, C.c_void_p)))
 
+    def exchange_info(self):
+        """dict(world, rank, fine_grained, connected) of the direct exchange set up on this handle."""
+        w, r, f, c = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.ccv_mppi_exchange_info(self._h, C.byref(w), C.byref(r), C.byref(f), C.byref(c)))
+        return {"world": w.value, "rank": r.value, "fine_grained": bool(f.value), "connected": bool(c.value)}
+
     def iterate_exchange_enqueue(self, x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration):
         x = self._x0(x0)
         xr, yr = capi.as_f64(x_ref, (self.H,)), capi.as_f64(y_ref, (self.H,))

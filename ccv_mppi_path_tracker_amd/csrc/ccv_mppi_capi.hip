@@ -4,10 +4,15 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -55,9 +60,14 @@ struct ccv_mppi_handle {
     ExchangeBox* box_peer[kMaxRanks] = {nullptr};   // every rank's box as mapped here ([xchg_rank] = d_box)
     bool box_opened[kMaxRanks] = {false};           // mapped with hipIpcOpenMemHandle (to be closed)
     double* d_xvec = nullptr;                       // reduced [sum w, sum w*u]
+    int32_t* d_xflag = nullptr;                     // device-side "a peer timed out" flag (sticky)
     int xchg_world = 0, xchg_rank = 0;
     bool xchg_connected = false;
+    bool box_fine_grained = false;                  // the box is fine-grained (device-coherent) memory
+    uint32_t xchg_nonce = 0;                        // this rank's contribution to the sequence base (rank 0's is used)
+    uint32_t xchg_base = 0;                         // sequence numbers start here: a restarted job does not match old packets
     unsigned long long xchg_seq = 0;
+    unsigned long long xchg_timeout_ticks = 1000000000ull;   // 10 s of the 100 MHz clock (CCV_MPPI_EXCHANGE_TIMEOUT_MS: tests)
     // queue-depth throttle for the asynchronous entry points: beyond a few dozen iterations in flight the HIP runtime's
     // enqueue path slows down several-fold (measured: 12 us/call at depth <= 64, 90 us/call at depth 512), so every
     // kThrottleEvery-th enqueue records an event and waits for the one recorded kThrottleSlots marks earlier
@@ -83,6 +93,7 @@ struct ccv_mppi_handle {
     int prio_rotate = 0, cu_count = 256;   // pc_rotate_priority (mppi_rollout_pc.h)
     int prune = 0;                         // pc_prune_window (mppi_rollout_pc.h)
     double inj_absmax[CCV_MPPI_MAX_UDIM] = {0, 0, 0, 0, 0};   // largest |control| per dimension in the buffer (sampled: clamp bound)
+    double nom_absmax[CCV_MPPI_MAX_UDIM] = {0, 0, 0, 0, 0};   // largest |u*| per dimension a caller has put there (ccv_mppi_set_nominal)
     // timing
     bool timing = false;
     int timing_every = 1;     // record events on every n-th iteration only
@@ -366,11 +377,12 @@ int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out, bool exch
         X.local = h->d_box;
         X.reduced = h->d_xvec;
         ++h->xchg_seq;
-        X.seq = (uint32_t)(h->xchg_seq % 0xFFFFFFFFull) + 1u;   // 1 .. 2^32-1, never 0 (the box starts zeroed)
+        X.seq = (uint32_t)(((unsigned long long)h->xchg_base + h->xchg_seq) % 0xFFFFFFFFull) + 1u;   // 1 .. 2^32-1, never 0 (the box starts zeroed)
+        X.timeout_flag = h->d_xflag;
         X.world = h->xchg_world;
         X.rank = h->xchg_rank;
         X.parity = (int)(h->xchg_seq & 1);
-        X.timeout_ticks = 1000000000ull;   // 10 s of the 100 MHz clock: a peer that never arrives yields NaN, not a hang
+        X.timeout_ticks = h->xchg_timeout_ticks;   // a peer that never arrives yields NaN and a flag, not a hang
         hipLaunchKernelGGL(k_finalize_exchange, dim3(finalize_blocks(h->R)), dim3(kBlock), 0, h->stream, F, X);
         HIP_TRY(h, hipGetLastError());
         h->pending_vec = h->d_xvec;   // u* = reduced[1..] / reduced[0]: deferred like ccv_mppi_apply_partials_enqueue
@@ -495,6 +507,59 @@ int fetch_result(ccv_mppi_handle* h, double* u_opt_out, ccv_mppi_stats* stats) {
     return CCV_MPPI_OK;
 }
 
+
+// ---- direct exchange: what travels between the ranks at set-up, and the boxes this process owns -------------------------
+struct ExchangeBlob {
+    hipIpcMemHandle_t ipc;
+    int32_t fine_grained;   // the box is fine-grained memory (coherent across devices)
+    uint32_t nonce;         // rank 0's is the base of the sequence numbers
+    int32_t pid;
+    int32_t device;         // ordinal inside that process
+    char bus[24];           // PCI bus id of the device that holds the box
+};
+
+// Boxes created by THIS process: hipIpcOpenMemHandle refuses a handle of the opening process itself, so a process that
+// drives several handles (several devices from one process, or several shards on one device) maps them directly.
+struct OwnBox {
+    ExchangeBlob blob;
+    ExchangeBox* box;
+};
+std::mutex g_box_mutex;
+std::vector<OwnBox> g_boxes;
+
+void exchange_release(ccv_mppi_handle* h) {
+    for (int r = 0; r < kMaxRanks; ++r) {
+        if (h->box_opened[r] && h->box_peer[r]) (void)hipIpcCloseMemHandle(h->box_peer[r]);
+        h->box_opened[r] = false;
+        h->box_peer[r] = nullptr;
+    }
+    if (h->d_box) {
+        {
+            std::lock_guard<std::mutex> lock(g_box_mutex);
+            g_boxes.erase(std::remove_if(g_boxes.begin(), g_boxes.end(), [&](const OwnBox& b) { return b.box == h->d_box; }), g_boxes.end());
+        }
+        (void)hipFree(h->d_box);
+    }
+    if (h->d_xvec) (void)hipFree(h->d_xvec);
+    if (h->d_xflag) (void)hipFree(h->d_xflag);
+    if (h->pending_vec == h->d_xvec) h->pending_vec = nullptr;
+    h->d_box = nullptr;
+    h->d_xvec = nullptr;
+    h->d_xflag = nullptr;
+    h->xchg_connected = false;
+    h->xchg_world = h->xchg_rank = 0;
+}
+
+// After a synchronisation: did the exchange kernel give up waiting for a peer?  (sticky: the controls are NaN from then on)
+int exchange_check(ccv_mppi_handle* h) {
+    if (!h->d_xflag) return CCV_MPPI_OK;
+    int32_t flag = 0;
+    HIP_TRY(h, hipMemcpy(&flag, h->d_xflag, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag)
+        return fail(h, CCV_MPPI_ERR_TIMEOUT, "direct exchange: a peer's partial vector did not arrive within 10 s; the controls are NaN "
+                                            "from that iteration on (destroy the handles and set the exchange up again)");
+    return CCV_MPPI_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -606,16 +671,23 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
 
 int ccv_mppi_destroy(ccv_mppi_handle* h) {
     if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    // everything below belongs to the handle's device; the caller's current device is put back afterwards
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->throttle_ev)
         if (e) (void)hipEventDestroy(e);
-    double* bufs[] = {h->d_nominal, h->d_u, h->d_xs, h->d_ys, h->d_cost, h->d_w, h->d_partial, h->d_statpart,
-                      h->d_vec, h->d_stats, h->d_cmin, h->d_scratch};
-    for (double* b : bufs)
+    exchange_release(h);
+    void* bufs[] = {h->d_nominal, h->d_u, h->d_xs, h->d_ys, h->d_cost, h->d_w, h->d_partial, h->d_statpart, h->d_vec, h->d_stats,
+                    h->d_cmin, h->d_scratch, h->d_frame, h->d_path, h->d_trace, h->d_dbg};
+    for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (prev >= 0 && prev != h->cfg.device) (void)hipSetDevice(prev);
     delete h;
     return CCV_MPPI_OK;
 }
@@ -657,7 +729,7 @@ int ccv_mppi_synchronize(ccv_mppi_handle* h) {
     if (!h) return CCV_MPPI_ERR_INVALID_ARG;
     if (int rc = flush_pending(h)) return rc;   // (after this the caller may free the partials buffer)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return CCV_MPPI_OK;
+    return exchange_check(h);
 }
 
 int ccv_mppi_set_nominal(ccv_mppi_handle* h, const double* u) {
@@ -665,6 +737,12 @@ int ccv_mppi_set_nominal(ccv_mppi_handle* h, const double* u) {
     h->pending_vec = nullptr;   // overwritten anyway
     HIP_TRY(h, hipMemcpyAsync(h->d_nominal, u, (size_t)h->R * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // (the resident loop's plant integrates u*[0]: its angle bounds must cover what the caller put there; NaN sticks)
+    for (int d = 0; d < CCV_MPPI_MAX_UDIM; ++d) h->nom_absmax[d] = 0.0;
+    for (int n = 0; n < h->R; ++n) {
+        const int d = n % h->udim;
+        if (!(std::fabs(u[n]) <= h->nom_absmax[d])) h->nom_absmax[d] = std::fabs(u[n]);
+    }
     return CCV_MPPI_OK;
 }
 
@@ -673,7 +751,7 @@ int ccv_mppi_get_nominal(ccv_mppi_handle* h, double* u) {
     if (int rc = flush_pending(h)) return rc;
     HIP_TRY(h, hipMemcpyAsync(u, h->d_nominal, (size_t)h->R * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return CCV_MPPI_OK;
+    return exchange_check(h);
 }
 
 int ccv_mppi_iterate(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref, const double* y_ref,
@@ -717,7 +795,7 @@ int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partia
 
 // ---- direct exchange between the devices of a node ------------------------------------------------------------------
 
-int ccv_mppi_exchange_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+int ccv_mppi_exchange_handle_bytes(void) { return (int)sizeof(ExchangeBlob); }
 
 int ccv_mppi_exchange_create(ccv_mppi_handle* h, int32_t world, int32_t rank, void* ipc_handle_out) {
     if (!h) return CCV_MPPI_ERR_INVALID_ARG;
@@ -726,32 +804,59 @@ int ccv_mppi_exchange_create(ccv_mppi_handle* h, int32_t world, int32_t rank, vo
     if (h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT)
         return fail(h, CCV_MPPI_ERR_INVALID_ARG, "MIN_SHIFT needs a cross-device min; not supported with partials");
     if (h->d_box) return fail(h, CCV_MPPI_ERR_STATE, "exchange already created");
-    // fine-grained (not cached across devices) when the allocation can be exported; otherwise ordinary device memory,
-    // which the kernel reads past the caches anyway
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    // Fine-grained memory: a peer's stores become visible to a kernel that is already running on the owner.  Ordinary
+    // (coarse-grained) device memory guarantees that only inside one device, so it is accepted as a fall-back only when
+    // every rank's box lives on this same device (ccv_mppi_exchange_connect checks; a one-device rehearsal).
     void* box = nullptr;
-    hipIpcMemHandle_t ipc;
+    ExchangeBlob blob;
+    std::memset(&blob, 0, sizeof(blob));
     hipError_t e = hipExtMallocWithFlags(&box, sizeof(ExchangeBox), hipDeviceMallocFinegrained);
-    if (e == hipSuccess) e = hipIpcGetMemHandle(&ipc, box);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&blob.ipc, box);
+    blob.fine_grained = e == hipSuccess ? 1 : 0;
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (box) (void)hipFree(box);
         box = nullptr;
         HIP_TRY(h, hipMalloc(&box, sizeof(ExchangeBox)));
-        e = hipIpcGetMemHandle(&ipc, box);
+        e = hipIpcGetMemHandle(&blob.ipc, box);
         if (e != hipSuccess) {
             (void)hipFree(box);
-            return fail(h, CCV_MPPI_ERR_HIP, "hipIpcGetMemHandle failed: no peer mapping on this system");
+            return fail(h, CCV_MPPI_ERR_HIP, "hipIpcGetMemHandle failed: no peer mapping on this system", e);
         }
     }
-    HIP_TRY(h, hipMemset(box, 0, sizeof(ExchangeBox)));
     h->d_box = static_cast<ExchangeBox*>(box);
-    HIP_TRY(h, hipMalloc(&h->d_xvec, (size_t)(h->R + 1) * sizeof(double)));
-    HIP_TRY(h, hipMemset(h->d_xvec, 0, (size_t)(h->R + 1) * sizeof(double)));
-    HIP_TRY(h, hipDeviceSynchronize());
+    auto undo = [&](int code, const char* what, hipError_t err) {
+        exchange_release(h);
+        return fail(h, code, what, err);
+    };
+    if ((e = hipMemset(box, 0, sizeof(ExchangeBox))) != hipSuccess) return undo(CCV_MPPI_ERR_HIP, "hipMemset(box)", e);
+    if ((e = hipMalloc(&h->d_xvec, (size_t)(h->R + 1) * sizeof(double))) != hipSuccess) return undo(CCV_MPPI_ERR_ALLOC, "hipMalloc(xvec)", e);
+    if ((e = hipMemset(h->d_xvec, 0, (size_t)(h->R + 1) * sizeof(double))) != hipSuccess) return undo(CCV_MPPI_ERR_HIP, "hipMemset(xvec)", e);
+    if ((e = hipMalloc(&h->d_xflag, sizeof(int32_t))) != hipSuccess) return undo(CCV_MPPI_ERR_ALLOC, "hipMalloc(xflag)", e);
+    if ((e = hipMemset(h->d_xflag, 0, sizeof(int32_t))) != hipSuccess) return undo(CCV_MPPI_ERR_HIP, "hipMemset(xflag)", e);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return undo(CCV_MPPI_ERR_HIP, "hipDeviceSynchronize", e);
+    blob.pid = (int32_t)getpid();
+    blob.device = h->cfg.device;
+    if (hipDeviceGetPCIBusId(blob.bus, (int)sizeof(blob.bus), h->cfg.device) != hipSuccess) std::snprintf(blob.bus, sizeof(blob.bus), "dev%d", h->cfg.device);
+    blob.bus[sizeof(blob.bus) - 1] = 0;
+    // sequence base: a job that is started again must not take the packets an earlier one left in a peer's box for its own
+    const uint64_t now = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+    blob.nonce = (uint32_t)(now ^ (now >> 29) ^ ((uint64_t)blob.pid * 0x9E3779B97F4A7C15ull >> 17));
+    h->xchg_nonce = blob.nonce;
+    if (const char* tv = std::getenv("CCV_MPPI_EXCHANGE_TIMEOUT_MS")) {
+        const long ms = std::atol(tv);
+        if (ms > 0) h->xchg_timeout_ticks = (unsigned long long)ms * 100000ull;
+    }
+    h->box_fine_grained = blob.fine_grained != 0;
     h->xchg_world = world;
     h->xchg_rank = rank;
     h->xchg_seq = 0;
-    std::memcpy(ipc_handle_out, &ipc, sizeof(ipc));
+    {
+        std::lock_guard<std::mutex> lock(g_box_mutex);
+        g_boxes.push_back(OwnBox{blob, h->d_box});
+    }
+    std::memcpy(ipc_handle_out, &blob, sizeof(blob));
     return CCV_MPPI_OK;
 }
 
@@ -760,24 +865,68 @@ int ccv_mppi_exchange_connect(ccv_mppi_handle* h, const void* ipc_handles) {
     if (!ipc_handles) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "ipc_handles is null");
     if (!h->d_box) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_exchange_create first");
     if (h->xchg_connected) return fail(h, CCV_MPPI_ERR_STATE, "exchange already connected");
-    const char* bytes = static_cast<const char*>(ipc_handles);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const ExchangeBlob* blobs = static_cast<const ExchangeBlob*>(ipc_handles);
+    ExchangeBlob mine;
+    std::memcpy(&mine, &blobs[h->xchg_rank], sizeof(mine));   // (the caller's buffer need not be aligned)
+    auto undo = [&](int code, const char* what, hipError_t err) {
+        for (int r = 0; r < kMaxRanks; ++r) {
+            if (h->box_opened[r] && h->box_peer[r]) (void)hipIpcCloseMemHandle(h->box_peer[r]);
+            h->box_opened[r] = false;
+            h->box_peer[r] = nullptr;
+        }
+        return fail(h, code, what, err);
+    };
     for (int r = 0; r < h->xchg_world; ++r) {
+        ExchangeBlob peer;
+        std::memcpy(&peer, reinterpret_cast<const char*>(ipc_handles) + (size_t)r * sizeof(ExchangeBlob), sizeof(peer));
+        peer.bus[sizeof(peer.bus) - 1] = 0;
         if (r == h->xchg_rank) {
             h->box_peer[r] = h->d_box;
             continue;
         }
-        hipIpcMemHandle_t ipc;
-        std::memcpy(&ipc, bytes + (size_t)r * sizeof(ipc), sizeof(ipc));
+        if ((!peer.fine_grained || !mine.fine_grained) && std::strcmp(peer.bus, mine.bus) != 0)
+            return undo(CCV_MPPI_ERR_STATE, "direct exchange refused: a box in coarse-grained memory would be polled across devices "
+                                            "(fine-grained allocation or its IPC export failed); use the all-reduce path", hipSuccess);
+        // a box of this very process (several handles driven by one process) is used as it is
+        ExchangeBox* local = nullptr;
+        if (peer.pid == (int32_t)getpid()) {
+            std::lock_guard<std::mutex> lock(g_box_mutex);
+            for (const OwnBox& b : g_boxes)
+                if (std::memcmp(&b.blob.ipc, &peer.ipc, sizeof(peer.ipc)) == 0 && b.blob.nonce == peer.nonce) local = b.box;
+        }
+        if (local) {
+            if (peer.device != h->cfg.device) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(peer.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return undo(CCV_MPPI_ERR_HIP, "hipDeviceEnablePeerAccess", pe);
+                (void)hipGetLastError();
+            }
+            h->box_peer[r] = local;
+            continue;
+        }
         void* p = nullptr;
-        HIP_TRY(h, hipIpcOpenMemHandle(&p, ipc, hipIpcMemLazyEnablePeerAccess));
+        hipError_t e = hipIpcOpenMemHandle(&p, peer.ipc, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return undo(CCV_MPPI_ERR_HIP, "hipIpcOpenMemHandle", e);
         h->box_peer[r] = static_cast<ExchangeBox*>(p);
         h->box_opened[r] = true;
         // touch the mapping through the runtime first: a mapping that cannot be used fails here with an error code
         // instead of faulting in a kernel
         unsigned long long probe = 0;
-        HIP_TRY(h, hipMemcpy(&probe, p, sizeof(probe), hipMemcpyDeviceToHost));
+        if ((e = hipMemcpy(&probe, p, sizeof(probe), hipMemcpyDeviceToHost)) != hipSuccess) return undo(CCV_MPPI_ERR_HIP, "peer box not readable", e);
     }
+    ExchangeBlob first;
+    std::memcpy(&first, ipc_handles, sizeof(first));
+    h->xchg_base = first.nonce;
     h->xchg_connected = true;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_exchange_info(const ccv_mppi_handle* h, int32_t* world, int32_t* rank, int32_t* fine_grained, int32_t* connected) {
+    if (!h) return CCV_MPPI_ERR_INVALID_ARG;
+    if (world) *world = h->xchg_world;
+    if (rank) *rank = h->xchg_rank;
+    if (fine_grained) *fine_grained = (h->d_box && h->box_fine_grained) ? 1 : 0;
+    if (connected) *connected = h->xchg_connected ? 1 : 0;
     return CCV_MPPI_OK;
 }
 
@@ -834,18 +983,45 @@ namespace {
 int resident_step(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance, bool normalise, double* vec_out,
                   bool exchange = false) {
     if (!h) return CCV_MPPI_ERR_INVALID_ARG;
-    if (!(dt == dt)) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "dt is NaN");
+    // dt is the stride of the window index (dd:160-163): as ccv_mppi_calc_ref_path, only 0 < dt < inf is defined
+    const double stride = h->cfg.v_ref * dt / h->path_resolution;
+    if (!(dt > 0.0) || !std::isfinite(dt)) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "resident step: dt must be positive and finite");
     if (!h->d_frame || !h->have_pose) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_resident_set_path and _set_pose first");
+    if (!std::isfinite(stride) || stride < 0.0 || stride * h->H > 2.0e9)
+        return fail(h, CCV_MPPI_ERR_INVALID_ARG, "resident step: v_ref * dt / resolution is not a usable window stride");
+    // Bounds on |yaw|, |roll|, |pitch| of the resident pose, which the host never sees: the command u*[0] is a weighted mean
+    // of clamped samples (or what ccv_mppi_set_nominal put there), and the plant takes an angle modulo 2 pi once it leaves
+    // +-kAngleRebase (rebase_angle), so the bounds stay below kAngleRebase + one step for a loop of any length.
+    const ccv_mppi_config& c = h->cfg;
+    auto lim = [&](int d) {
+        const double a = std::fmax(std::fabs(c.u_min[d]), std::fabs(c.u_max[d]));
+        const double b = std::fmax(h->inj_absmax[d], h->nom_absmax[d]);
+        return (b == b) ? std::fmax(a, b) : b;   // NaN sticks
+    };
+    double nb[3] = {h->res_angle_abs[0], h->res_angle_abs[1], h->res_angle_abs[2]};
+    if (advance) {
+        auto step = [&](double bound, int d) {
+            const double after = bound + lim(d) * dt;
+            return after <= kAngleRebase ? after : (after == after ? kAngleRebase : after);   // (beyond it the plant re-bases: |angle| <= pi)
+        };
+        nb[0] = step(nb[0], 1);
+        if (c.model == CCV_MPPI_FULL_BODY) {
+            nb[1] = step(nb[1], 3);
+            nb[2] = step(nb[2], 4);
+        }
+    }
+    // everything that can refuse the step is checked BEFORE k_advance moves the pose
+    {
+        RolloutArgs chk;
+        const double bounds[5] = {0.0, 0.0, nb[0], nb[1], nb[2]};
+        fill_args(h, chk, bounds, dt, 0.0, seed, iter);
+        // k_advance itself takes sin / cos of the OLD heading (+ the steering command)
+        const double heading_bound = h->res_angle_abs[0] + (c.model == CCV_MPPI_DIFF_DRIVE ? 0.0 : lim(2));
+        if (!h->coop || !fast_trig_safe(h, chk, MODE_FUSED) || !(heading_bound <= kFastTrigLimit))
+            return fail(h, CCV_MPPI_ERR_STATE, "the resident loop needs the cooperative kernels and bounded pose angles / commands");
+    }
     if (advance) {
         if (int rc = flush_pending(h)) return rc;   // the command is u*[0]: a deferred division has to happen now
-        // u* is a weighted mean of clamped samples (or what ccv_mppi_set_nominal put there): bound the angles it can reach
-        const ccv_mppi_config& c = h->cfg;
-        auto lim = [&](int d) { return std::fmax(std::fmax(std::fabs(c.u_min[d]), std::fabs(c.u_max[d])), h->inj_absmax[d]); };
-        h->res_angle_abs[0] += lim(1) * std::fabs(dt);
-        if (c.model == CCV_MPPI_FULL_BODY) {
-            h->res_angle_abs[1] += lim(3) * std::fabs(dt);
-            h->res_angle_abs[2] += lim(4) * std::fabs(dt);
-        }
     }
     AdvanceArgs V;
     V.frame = h->d_frame;
@@ -864,7 +1040,8 @@ int resident_step(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, i
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(kAdvanceThreads), 0, h->stream, V);
     HIP_TRY(h, hipGetLastError());
     h->res_steps += 1;
-    const double bounds[5] = {0.0, 0.0, h->res_angle_abs[0], h->res_angle_abs[1], h->res_angle_abs[2]};
+    for (int i = 0; i < 3; ++i) h->res_angle_abs[i] = nb[i];
+    const double bounds[5] = {0.0, 0.0, nb[0], nb[1], nb[2]};
     return enqueue_iteration(h, bounds, dt, nullptr, nullptr, 0.0, seed, iter, normalise, vec_out, true, exchange);
 }
 }  // namespace

@@ -26,6 +26,14 @@ int nearest_index(const double* px, const double* py, int n, double x, double y)
 // sin and cos as the device computes them (csrc/fast_trig.h fast_sincos, restated operation by operation: three-step
 // Cody-Waite reduction by pi/2, fdlibm kernel polynomials, quadrant selection), so that a pose advanced here and one
 // advanced by k_advance on the device are the same bits.  |x| <= 1e5 as on the device; at most 1 ulp from libm.
+// csrc/fast_trig.h rebase_angle(), restated (this file is compiled without the HIP headers)
+double rebase_angle(double a) {
+    if (!(std::fabs(a) > 1.0e4)) return a;
+    const double n = std::rint(a * 1.59154943091895345608e-01);
+    a = std::fma(-n, 6.28318530717958623200e+00, a);
+    return std::fma(-n, 2.44929359829470641435e-16, a);
+}
+
 void spec_sincos(double x, double& s, double& c) {
     const double fn = std::rint(x * 6.36619772367581382433e-01);
     double r = std::fma(-fn, 1.57079632673412561417e+00, x);
@@ -61,6 +69,13 @@ int ccv_mppi_calc_ref_path(const double* path_x, const double* path_y, int32_t n
                            double v_ref, double dt, double resolution, int32_t horizon, double* x_ref, double* y_ref,
                            double* yaw_ref) {
     if (!path_x || !path_y || !x_ref || !y_ref || !yaw_ref || n_path < 1 || horizon < 2) return CCV_MPPI_ERR_INVALID_ARG;
+    // The window index start + i * stride is the truncation of a double (dd:160-163).  The node takes dt from its clock
+    // (dd:346-348); a non-positive or non-finite dt, v_ref or resolution makes that index negative or undefined (the
+    // reference then reads outside path_): refused here, and in the same way by the device-resident prologue.
+    {
+        const double stride_chk = v_ref * dt / resolution;
+        if (!(dt > 0.0) || !std::isfinite(stride_chk) || stride_chk < 0.0 || stride_chk * horizon > 2.0e9) return CCV_MPPI_ERR_INVALID_ARG;
+    }
     const int start = nearest_index(path_x, path_y, n_path, cur_x, cur_y);
     // window stride in path indices; the index is the truncation of a double (dd:160-163)
     const double stride = v_ref * dt / resolution;
@@ -117,10 +132,11 @@ int ccv_mppi_plant_step(int32_t model, double* state, const double* u, double dt
     spec_sincos(heading, sn, cs);
     state[0] = state[0] + u[0] * cs * dt;
     state[1] = state[1] + u[0] * sn * dt;
-    state[2] = state[2] + u[1] * dt;
+    // (angles beyond +-1e4 rad are taken modulo 2 pi, exactly as k_advance does on the device: csrc/fast_trig.h)
+    state[2] = rebase_angle(state[2] + u[1] * dt);
     if (model == CCV_MPPI_FULL_BODY) {
-        state[3] = state[3] + u[3] * dt;
-        state[4] = state[4] + u[4] * dt;
+        state[3] = rebase_angle(state[3] + u[3] * dt);
+        state[4] = rebase_angle(state[4] + u[4] * dt);
     }
     return CCV_MPPI_OK;
 }

@@ -15,6 +15,17 @@ namespace ccv {
 
 constexpr double kFastTrigLimit = 1.0e5;
 
+// The closed-loop plant (k_advance, ccv_mppi_plant_step) integrates yaw / roll / pitch without bound, where the real node
+// reads them from tf in [-pi, pi].  An angle that leaves +-kAngleRebase is taken modulo 2 pi (two-step Cody-Waite, the
+// same operations on host and device), so a loop of any length stays inside the branch-free sin/cos range.
+constexpr double kAngleRebase = 1.0e4;
+__host__ __device__ inline double rebase_angle(double a) {
+    if (!(fabs(a) > kAngleRebase)) return a;   // (NaN: unchanged)
+    const double n = rint(a * 1.59154943091895345608e-01);     // 1 / (2 pi)
+    a = fma(-n, 6.28318530717958623200e+00, a);               // 2 pi, rounded to double
+    return fma(-n, 2.44929359829470641435e-16, a);            // 2 pi - the above
+}
+
 __device__ __forceinline__ bool fast_trig_ok(double x) { return fabs(x) <= kFastTrigLimit; }   // false for NaN/Inf
 
 __device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {

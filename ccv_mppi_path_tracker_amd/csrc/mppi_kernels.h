@@ -612,6 +612,7 @@ struct ExchangeArgs {
     uint32_t seq;                   // this exchange's sequence number, never 0
     int32_t world, rank, parity;
     unsigned long long timeout_ticks;   // s_memrealtime ticks (100 MHz) to wait for the peers; then `reduced` is NaN
+    int32_t* timeout_flag;              // set to 1 when that happens (the host reports it at the next synchronisation)
 };
 
 __device__ __forceinline__ unsigned long long load_system(const unsigned long long* p) {   // past every cache
@@ -664,7 +665,10 @@ __global__ __launch_bounds__(kBlock) void k_finalize_exchange(const FinalizeArgs
     const double theirs = __longlong_as_double((long long)((hi & 0xFFFFFFFF00000000ull) | (lo >> 32)));
     double acc = 0.0;
     for (int r = 0; r < X.world; ++r) acc += lane_value(theirs, r);   // rank order on every device
-    if (lane == 0) X.reduced[slot] = ok ? acc : __builtin_nan("");
+    if (lane == 0) {
+        X.reduced[slot] = ok ? acc : __builtin_nan("");
+        if (!ok && X.timeout_flag) *X.timeout_flag = 1;
+    }
 }
 
 // After the cross-device all-reduce of [sum w, sum w*u]: u* = V / S on every device.

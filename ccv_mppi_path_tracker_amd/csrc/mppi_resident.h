@@ -45,10 +45,10 @@ __global__ __launch_bounds__(kAdvanceThreads) void k_advance(const AdvanceArgs A
         fast_sincos(heading, sn, cs);
         x = x + v * cs * A.dt;
         y = y + v * sn * A.dt;
-        yaw = yaw + w * A.dt;
+        yaw = rebase_angle(yaw + w * A.dt);
         if (A.model == CCV_MPPI_FULL_BODY) {
-            roll = roll + A.nominal[3] * A.dt;
-            pitch = pitch + A.nominal[4] * A.dt;
+            roll = rebase_angle(roll + A.nominal[3] * A.dt);
+            pitch = rebase_angle(pitch + A.nominal[4] * A.dt);
         }
     }
     // ---- get_CurrentIndex(): strict '<' against a running minimum that starts at the 100 m gate
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kAdvanceThreads) void k_advance(const AdvanceArgs A
     // ---- calc_RefPath(): the index is the truncation of a double; past the end the final pose repeats
     const double stride = A.v_ref * A.dt / A.resolution;
     for (int i = threadIdx.x; i < A.H; i += kAdvanceThreads) {
-        const int idx = (int)(start + i * stride);
+        const int idx = (int)(start + i * stride);   // (the host admits 0 < dt < inf only: idx >= 0)
         const int src = idx < A.n_path ? idx : A.n_path - 1;
         const double xr = A.path_x[src], yr = A.path_y[src];
         F.x_ref[i] = xr;

@@ -35,7 +35,7 @@ class ShardedMPPI:
         if hasattr(self.backend, "iterate"):   # the backend exchanges the partials itself (ExchangeBackend)
             return self.backend.iterate(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration)
         part = self.backend.local_partials(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration)
-        if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
+        if self.dist.is_initialized():   # (also with one rank: the same call sequence whatever the world size)
             self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM, group=self.group)
         self.backend.apply(part)
         return part
@@ -47,7 +47,7 @@ class ShardedMPPI:
         if hasattr(self.backend, "iterate_resident"):   # ExchangeBackend
             return self.backend.iterate_resident(dt, seed, iteration, advance)
         part = self.backend.local_partials_resident(dt, seed, iteration, advance)
-        if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
+        if self.dist.is_initialized():
             self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM, group=self.group)
         self.backend.apply(part)
         return part
@@ -114,6 +114,7 @@ class ExchangeBackend:
             dist.all_gather_object(flags, bool(good), group=group)
             good = all(flags)
         self.ok = bool(good)
+        self.info = controller.exchange_info() if mine is not None else {}
 
     def iterate(self, x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration):
         self.ctl.iterate_exchange_enqueue(x0, dt, x_ref, y_ref, yaw_ref0, seed, iteration)

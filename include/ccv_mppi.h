@@ -42,6 +42,7 @@ extern "C" {
 #define CCV_MPPI_ERR_HIP (-3)
 #define CCV_MPPI_ERR_STATE (-4) /* stage-wise calls in the wrong order */
 #define CCV_MPPI_ERR_ALLOC (-5)
+#define CCV_MPPI_ERR_TIMEOUT (-6) /* direct exchange: a peer's partial vector never arrived (reported at the next synchronisation) */
 
 /* controller model; u_dim = 2 / 3 / 5, control order = declaration order of the reference
  * (dd: v,w  sd: v,w,steer  fb: v,w,direction,roll_v,pitch_v) */
@@ -162,10 +163,20 @@ int ccv_mppi_apply_partials_enqueue(ccv_mppi_handle* h, const double* dev_partia
  * processes exchange the returned handles (ccv_mppi_exchange_handle_bytes() bytes each, e.g. torch.distributed
  * all_gather), then every process calls _connect with all of them in rank order.  Every rank must then issue the same
  * sequence of ccv_mppi_iterate_exchange_enqueue calls; a peer that does not arrive within 10 s yields NaN controls, not a
- * hang.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only supports dmabuf IPC. */
+ * hang, and the next ccv_mppi_synchronize / ccv_mppi_get_nominal on that handle returns CCV_MPPI_ERR_TIMEOUT (the *_enqueue
+ * calls themselves cannot know).  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only supports dmabuf IPC.
+ * The box is fine-grained (device-coherent) memory; where that cannot be allocated or exported it falls back to ordinary
+ * device memory, which _connect accepts only if every rank's box lives on the same physical device (a one-device
+ * rehearsal) and refuses with CCV_MPPI_ERR_STATE otherwise -- the caller then takes the all-reduce path above.
+ * Handles of one process (one process driving several devices) connect to each other directly, without hipIpc.
+ * The blob a rank hands out also carries a nonce; rank 0's is the base of the packet sequence numbers, so a job that is
+ * started again does not mistake packets of an earlier one for its own. */
 int ccv_mppi_exchange_handle_bytes(void);
 int ccv_mppi_exchange_create(ccv_mppi_handle* h, int32_t world, int32_t rank, void* ipc_handle_out);
 int ccv_mppi_exchange_connect(ccv_mppi_handle* h, const void* ipc_handles);
+/* What was set up (any pointer may be NULL): world, rank, whether this handle's box is fine-grained memory, whether
+ * _connect has succeeded. */
+int ccv_mppi_exchange_info(const ccv_mppi_handle* h, int32_t* world, int32_t* rank, int32_t* fine_grained, int32_t* connected);
 int ccv_mppi_iterate_exchange_enqueue(ccv_mppi_handle* h, const double* x0, double dt, const double* x_ref,
                                       const double* y_ref, double yaw_ref0, uint64_t seed, uint64_t iter);
 
@@ -179,7 +190,14 @@ int ccv_mppi_iterate_exchange_enqueue(ccv_mppi_handle* h, const double* x0, doub
  * and pose are bit-identical to ccv_mppi_calc_ref_path() / ccv_mppi_plant_step() on the host; yaw_ref[0] (read by fb:408
  * only) comes from the device atan2 and may differ from libm's in the last place.  v_ref and the horizon are the
  * handle's; `resolution` is the spacing of the path poses (resolution_, dd:160).  Needs the default (cooperative)
- * kernels. */
+ * kernels.
+ * dt must be positive and finite (it is the stride of the window index, dd:160-163; the reference's behaviour for anything
+ * else is undefined): CCV_MPPI_ERR_INVALID_ARG otherwise, as from ccv_mppi_calc_ref_path().
+ * The plant takes yaw / roll / pitch modulo 2 pi once they leave +-1e4 rad (the real node reads them from tf in [-pi, pi]),
+ * identically in ccv_mppi_plant_step(), so a loop of any length stays inside the range of the kernels' branch-free
+ * sin/cos.  A step is refused with CCV_MPPI_ERR_STATE -- before the pose is moved -- when the pose angles (as set by
+ * _set_pose) or the commands (clamp bounds, and whatever ccv_mppi_set_nominal put into u*) can leave that range (1e5 rad)
+ * within one horizon. */
 int ccv_mppi_resident_set_path(ccv_mppi_handle* h, const double* path_x, const double* path_y, int32_t n_path,
                                double resolution);
 /* state: (x, y, yaw[, roll, pitch]); also restarts the step counter and the trace */

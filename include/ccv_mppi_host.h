@@ -21,7 +21,10 @@ extern "C" {
 #endif
 
 /* Fills x_ref[H], y_ref[H], yaw_ref[H-1] (yaw_ref[H-1] is left untouched, as in the reference) and returns
- * current_index_ (>= 0), or a negative CCV_MPPI_ERR_* code. */
+ * current_index_ (>= 0), or a negative CCV_MPPI_ERR_* code.  The window index is the truncation of
+ * current_index + i * v_ref * dt / resolution (dd:160-163) and the node takes dt from its clock (dd:346-348): a dt that
+ * is not positive and finite, or a stride that is negative / not finite, would index before path_[0] (undefined behaviour
+ * in the reference) and is refused with CCV_MPPI_ERR_INVALID_ARG. */
 int ccv_mppi_calc_ref_path(const double* path_x, const double* path_y, int32_t n_path, double cur_x, double cur_y,
                            double v_ref, double dt, double resolution, int32_t horizon, double* x_ref, double* y_ref,
                            double* yaw_ref);
@@ -37,7 +40,8 @@ int ccv_mppi_path_dkan(double resolution, double* path_x, double* path_y, int32_
 
 /* state (x, y, yaw[, roll, pitch]) advanced one Euler step with the controls u (model's control order).  sin / cos of
  * the heading are the specified polynomial evaluation the device uses (<= 1 ulp from libm), so that this and the resident
- * loop's plant (ccv_mppi_resident_step_enqueue, ccv_mppi.h) give the same bits; |heading| <= 1e5. */
+ * loop's plant (ccv_mppi_resident_step_enqueue, ccv_mppi.h) give the same bits; |heading| <= 1e5.  yaw / roll / pitch beyond
+ * +-1e4 rad are taken modulo 2 pi after the step (the node reads them from tf in [-pi, pi]); the device plant does the same. */
 int ccv_mppi_plant_step(int32_t model, double* state, const double* u, double dt);
 
 #ifdef __cplusplus

@@ -750,3 +750,166 @@ def test_exchange_processes_on_one_device(tmp_path, world):
     for it in range(iters):
         whole.iterate_enqueue(state, p.dt, xr, yr, yaw[0], 5, it)
     np.testing.assert_allclose(u0, whole.get_nominal(), rtol=1e-7, atol=1e-10)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# exact window pruning (pc_prune_window): the loop over the pruned hull must give the same bits as the full loop
+# --------------------------------------------------------------------------------------------------------------
+def _awkward_window(kind, H, state, rng):
+    if kind == "path":
+        return None
+    if kind == "random":
+        return rng.uniform(-3, 3, H), rng.uniform(-3, 3, H)
+    if kind == "circle":
+        a = np.linspace(0, 2 * np.pi, H, endpoint=False)
+        return state[0] + 1.5 * np.cos(a), state[1] + 1.5 * np.sin(a)
+    if kind == "duplicates":
+        xr, yr = np.full(H, 1.0), np.full(H, 0.5)
+        xr[::7] += 0.8
+        return xr, yr
+    if kind == "far":
+        return np.linspace(150.0, 160.0, H), np.linspace(-90.0, -80.0, H)
+    if kind == "line_behind":
+        return state[0] - np.linspace(0.0, 4.0, H), np.full(H, state[1] + 0.2)
+    if kind == "nan_point":
+        xr, yr = rng.uniform(-2, 2, H), rng.uniform(-2, 2, H)
+        xr[H // 3] = np.nan
+        yr[2 * H // 3] = np.nan
+        return xr, yr
+    if kind == "inf_point":
+        xr, yr = np.linspace(0.0, 5.0, H), np.zeros(H)
+        xr[H // 2] = np.inf
+        yr[H - 2] = -np.inf
+        return xr, yr
+    if kind == "huge":
+        return np.linspace(0.0, 5.0, H) * 1e150, np.linspace(-1.0, 1.0, H) * 1e150   # overflows fp32 (and d^2 in fp64)
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["path", "random", "circle", "duplicates", "far", "line_behind", "nan_point", "inf_point", "huge"])
+@pytest.mark.parametrize("wl,K,H,kernel", [("C2", 1000, 50, None), ("C2", 1000, 50, "solo"), ("C3", 640, 50, None),
+                                           ("C4", 512, 80, "solo"), ("C4", 256, 128, None), ("C2", 320, 67, "pc")])
+def test_pruned_loop_equals_full_loop_bitwise(monkeypatch, kind, wl, K, H, kernel):
+    """CCV_MPPI_PRUNE=1 (dominance test + loop over the hull of the survivors) against CCV_MPPI_PRUNE=0 (every window point
+    for every state), same kernel: per-sample costs, weights and u* must be the same bits -- the test only ever removes
+    points that cannot be the minimum -- for path-like windows and for windows that are unordered, closed, degenerate, far
+    away or contain NaN / infinite / huge coordinates.  Three iterations (the warm start moves the samples)."""
+    w = configs.workload(wl, num_samples=K, horizon=H)
+    p = w.params
+    rng = np.random.default_rng(3)
+    path = helpers.oracle_path(w.path)
+    state = np.zeros(p.nstate)
+    state[:3] = path[0][0] + 0.4, path[1][0] - 0.3, 0.3
+    win = _awkward_window(kind, H, state, rng)
+    if win is None:
+        xr, yr, yaw = helpers.oracle_window(p, path, state)
+        yaw0 = yaw[0]
+    else:
+        (xr, yr), yaw0 = win, 0.1
+    if kernel:
+        monkeypatch.setenv("CCV_MPPI_KERNEL", kernel)
+    monkeypatch.setenv("CCV_MPPI_PRUNE", "1")
+    a = MPPIController(p)
+    monkeypatch.setenv("CCV_MPPI_PRUNE", "0")
+    b = MPPIController(p)
+    for it in range(3):
+        ua, sa = a.iterate(state, p.dt, xr, yr, yaw0, 4, it)
+        ub, sb = b.iterate(state, p.dt, xr, yr, yaw0, 4, it)
+        np.testing.assert_array_equal(a.read_costs(), b.read_costs())
+        np.testing.assert_array_equal(ua, ub)
+        assert sa.sum_w == sb.sum_w or (np.isnan(sa.sum_w) and np.isnan(sb.sum_w))
+        if not np.all(np.isfinite(ua)):   # (all weights underflowed / NaN: the next warm start is NaN for both -- SURVEY Q4)
+            break
+    if kind in ("path", "random", "circle", "line_behind") and wl != "C4":   # (full body far from its path: every weight underflows)
+        assert np.all(np.isfinite(ua))
+
+
+def test_pruned_loop_with_nonfinite_positions(monkeypatch):
+    """Samples whose positions are NaN or infinite (here: through an infinite speed bound and a NaN in the warm start) end at
+    the 100 m gate value whatever the loop covers; the finite lanes of the same wave must be unaffected by them."""
+    p = configs.diff_drive_defaults(512, 40).with_(u_min=(-1e308, -2.0), u_max=(1e308, 2.0), control_noise=1e306)
+    path = helpers.oracle_path("sinusoid")
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    monkeypatch.setenv("CCV_MPPI_PRUNE", "1")
+    a = MPPIController(p)
+    monkeypatch.setenv("CCV_MPPI_PRUNE", "0")
+    b = MPPIController(p)
+    a.iterate(state, p.dt, xr, yr, yaw[0], 9, 0)
+    b.iterate(state, p.dt, xr, yr, yaw[0], 9, 0)
+    np.testing.assert_array_equal(a.read_costs(), b.read_costs())
+
+
+# --------------------------------------------------------------------------------------------------------------
+# lifetime: ccv_mppi_destroy gives everything back
+# --------------------------------------------------------------------------------------------------------------
+def test_create_destroy_returns_all_device_memory():
+    """create -> device-resident loop + direct exchange set up -> a few iterations -> destroy, 200 times: the free device
+    memory (hipMemGetInfo) must come back to where it started.  (Round 1 leaked the resident frame, path, trace and the
+    exchange box: ~0.7 MB per handle.)"""
+    import torch
+    from ccv_mppi_path_tracker_amd import sharded
+    w = configs.workload("C4", num_samples=2048, horizon=40)
+    p = w.params
+    px, py = amd.make_path(w.path)
+    state = start_state(p, (px, py))
+
+    def cycle():
+        g = MPPIController(p)
+        g.resident_set_path(px, py)
+        g.resident_set_pose(state)
+        xb = sharded.ExchangeBackend(g)
+        assert xb.ok
+        g.resident_step_enqueue(p.dt, 1, 0, advance=False)
+        g.resident_step_exchange_enqueue(p.dt, 1, 1, advance=True)
+        g.read_top_candidates(4)        # (allocates the read-back scratch)
+        assert np.all(np.isfinite(g.get_nominal()))
+        g.close()
+
+    for _ in range(3):   # runtime pools settle
+        cycle()
+    torch.cuda.synchronize()
+    free0, _total = torch.cuda.mem_get_info()
+    for _ in range(200):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _total = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 * 2**20, "device memory shrank by %.1f MiB over 200 create/destroy cycles" % ((free0 - free1) / 2**20)
+
+
+def test_exchange_peer_timeout_is_reported(monkeypatch):
+    """Two ranks (two handles of this process), only rank 0 ever iterates: its update kernel gives up after the timeout
+    (shortened here), the controls are NaN, and the next synchronisation says why instead of returning OK."""
+    monkeypatch.setenv("CCV_MPPI_EXCHANGE_TIMEOUT_MS", "200")
+    p = configs.workload("C2", num_samples=1024).params
+    path = helpers.oracle_path("sinusoid")
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    a, b = MPPIController(p, num_samples=512), MPPIController(p, num_samples=512, sample_offset=512)
+    blobs = [a.exchange_create(2, 0), b.exchange_create(2, 1)]
+    a.exchange_connect(blobs)
+    b.exchange_connect(blobs)
+    assert a.exchange_info() == {"world": 2, "rank": 0, "fine_grained": a.exchange_info()["fine_grained"], "connected": True}
+    a.iterate_exchange_enqueue(state, p.dt, xr, yr, yaw[0], 5, 0)   # rank 1 never arrives
+    with pytest.raises(MPPIError) as e:
+        a.synchronize()
+    assert e.value.code == capi.ERR_TIMEOUT
+    with pytest.raises(MPPIError) as e:
+        a.get_nominal()
+    assert e.value.code == capi.ERR_TIMEOUT
+    # two ranks that do both arrive are fine (fresh handles; the flag of the old ones is sticky)
+    c, d = MPPIController(p, num_samples=512), MPPIController(p, num_samples=512, sample_offset=512)
+    blobs = [c.exchange_create(2, 0), d.exchange_create(2, 1)]
+    c.exchange_connect(blobs)
+    d.exchange_connect(blobs)
+    with pytest.raises(MPPIError):
+        c.exchange_connect(blobs)   # already connected
+    for it in range(6):
+        c.iterate_exchange_enqueue(state, p.dt, xr, yr, yaw[0], 5, it)
+        d.iterate_exchange_enqueue(state, p.dt, xr, yr, yaw[0], 5, it)
+    uc, ud = c.get_nominal(), d.get_nominal()
+    np.testing.assert_array_equal(uc, ud)
+    whole = MPPIController(p)
+    for it in range(6):
+        whole.iterate_enqueue(state, p.dt, xr, yr, yaw[0], 5, it)
+    np.testing.assert_allclose(uc, whole.get_nominal(), rtol=1e-8, atol=1e-12)

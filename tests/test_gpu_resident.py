@@ -218,3 +218,106 @@ def test_resident_errors():
         g.resident_step_enqueue(float("nan"), 1, 0)
     g.resident_step_enqueue(p.dt, 1, 0, advance=False)
     assert np.all(np.isfinite(g.get_nominal()))
+
+
+def test_resident_rejects_bad_dt_before_moving_the_pose():
+    """dt is the stride of the window index (dd:160-163): zero, negative and infinite periods are refused like NaN, on the
+    device path and in ccv_mppi_calc_ref_path alike, and a refused step leaves the pose and the step counter alone."""
+    p = configs.diff_drive_defaults(256, 30)
+    px, py = amd.make_path("sinusoid")
+    g = MPPIController(p)
+    g.resident_set_path(px, py, 0.1)
+    g.resident_set_pose([0.3, 0.1, 0.2])
+    g.resident_step_enqueue(p.dt, 1, 0, advance=False)
+    before = g.resident_read()
+    for bad in (0.0, -0.1, float("inf"), float("-inf"), float("nan"), 1e300):
+        with pytest.raises(MPPIError) as e:
+            g.resident_step_enqueue(bad, 1, 1, advance=True)
+        assert e.value.code == capi.ERR_INVALID_ARG
+        with pytest.raises(MPPIError):
+            amd.calc_ref_path(px, py, 0.3, 0.1, p.v_ref, bad, p.resolution, p.horizon)
+    after = g.resident_read()
+    np.testing.assert_array_equal(before[0], after[0])
+    assert before[5] == after[5] == 1
+    with pytest.raises(MPPIError):
+        amd.calc_ref_path(px, py, 0.3, 0.1, -1.0, 0.1, p.resolution, p.horizon)   # negative stride
+
+
+@pytest.mark.parametrize("model", ["diff_drive", "full_body"])
+def test_resident_loop_runs_past_the_angle_limit(model):
+    """Round 1 bounded |yaw| of the resident pose by accumulation and refused every step once the bound passed 1e5 rad
+    (about 5e5 ticks at the C2 limits).  Now the plant takes an angle modulo 2 pi once it leaves +-1e4 rad, on the device
+    and in ccv_mppi_plant_step alike: a loop started just below that limit and turning hard crosses it, keeps running, and
+    stays the host loop bit for bit (diff drive); 3000 more ticks never refuse."""
+    w = configs.workload(WORKLOADS[model], num_samples=512, horizon=20)
+    p = w.params.with_(yaw_weight=0.0)   # (fb:408: 2 * (1e4)^2 would underflow every weight -- SURVEY Q15 / Q4)
+    px, py = amd.make_path("straight")
+    s0 = np.zeros(p.nstate)
+    s0[:3] = 1.0, 0.2, 1.0e4 - 0.35
+    turn = np.zeros((p.horizon - 1, p.udim))
+    turn[:, 0], turn[:, 1] = 0.5, p.u_max[1]      # warm start: turn left as hard as allowed
+    ticks, seed = 12, 5
+    g = MPPIController(p)
+    g.resident_set_path(px, py)
+    g.resident_set_pose(s0)
+    g.set_nominal(turn)
+    h = MPPIController(p)
+    h.set_nominal(turn)
+    s, u, crossed = s0.copy(), None, False
+    for it in range(ticks):
+        g.resident_step_enqueue(p.dt, seed, it, advance=it > 0)
+        if it > 0:
+            s = amd.plant_step(p.model, s, u[0], p.dt)
+        crossed = crossed or abs(s[2]) < 10.0
+        idx, xr, yr, yaw = amd.calc_ref_path(px, py, s[0], s[1], p.v_ref, p.dt, p.resolution, p.horizon)
+        u = h.iterate(s, p.dt, xr, yr, yaw[0], seed, it, want_stats=False)
+        if model == "diff_drive":
+            np.testing.assert_array_equal(g.resident_read()[0], s)
+            np.testing.assert_array_equal(g.get_nominal(), u)
+        else:
+            np.testing.assert_allclose(g.resident_read()[0], s, rtol=0, atol=1e-9)
+    assert crossed, "the loop never crossed the re-basing limit"
+    for it in range(ticks, ticks + 3000):
+        g.resident_step_enqueue(p.dt, seed, it, advance=True)
+    st = g.resident_read()[0]
+    assert np.all(np.isfinite(st)) and abs(st[2]) <= 1.0e4 + 1.0
+
+
+def test_resident_refuses_unbounded_angles_and_commands():
+    p = configs.diff_drive_defaults(256, 30)
+    px, py = amd.make_path("straight")
+    g = MPPIController(p)
+    g.resident_set_path(px, py)
+    g.resident_set_pose([0.0, 0.0, 2.0e5])                      # outside the sin/cos range from the start
+    with pytest.raises(MPPIError) as e:
+        g.resident_step_enqueue(p.dt, 1, 0, advance=False)
+    assert e.value.code == capi.ERR_STATE
+    g.resident_set_pose([0.0, 0.0, 9.0e4])                      # inside: runs, and the first advance re-bases it
+    g.resident_step_enqueue(p.dt, 1, 0, advance=False)
+    g.resident_step_enqueue(p.dt, 1, 1, advance=True)
+    assert abs(g.resident_read()[0][2]) <= np.pi + 1.0
+    # an absurd yaw RATE in a caller's warm start is harmless: the plant re-bases the yaw it produces
+    huge = np.zeros((p.horizon - 1, p.udim))
+    huge[0, 1] = 5.0e6
+    g.set_nominal(huge)
+    g.resident_step_enqueue(p.dt, 1, 2, advance=True)
+    assert abs(g.resident_read()[0][2]) <= np.pi and np.all(np.isfinite(g.get_nominal()))
+    # an absurd steering ANGLE is added to the heading before its sin / cos: part of the bound, refused before the pose moves
+    ps = configs.steering_defaults(256, 30)
+    gs = MPPIController(ps)
+    gs.resident_set_path(px, py)
+    gs.resident_set_pose([0.0, 0.0, 0.1])
+    gs.resident_step_enqueue(ps.dt, 1, 0, advance=False)
+    huge = np.zeros((ps.horizon - 1, ps.udim))
+    huge[0, 2] = 5.0e6
+    gs.set_nominal(huge)
+    before = gs.resident_read()
+    with pytest.raises(MPPIError) as e:
+        gs.resident_step_enqueue(ps.dt, 1, 1, advance=True)
+    assert e.value.code == capi.ERR_STATE
+    after = gs.resident_read()
+    np.testing.assert_array_equal(before[0], after[0])
+    assert before[5] == after[5]
+    gs.set_nominal(np.zeros((ps.horizon - 1, ps.udim)))
+    gs.resident_step_enqueue(ps.dt, 1, 1, advance=True)
+    assert np.all(np.isfinite(gs.get_nominal()))

@@ -38,6 +38,17 @@ def test_ref_window_rejects_bad_arguments():
     px, py = amd.make_path("straight")
     with pytest.raises(amd.controller.MPPIError):
         amd.calc_ref_path(px[:0], py[:0], 0.0, 0.0, 1.0, 0.1, 0.1, 10)
+    # the window index start + i * v_ref * dt / resolution is the truncation of a double (dd:160-163) and the node takes dt
+    # from its clock (dd:346-348): anything but a positive finite dt and a finite non-negative stride would index before
+    # path_[0] (undefined in the reference) and is refused
+    for dt in (0.0, -0.1, float("inf"), float("nan")):
+        with pytest.raises(amd.controller.MPPIError):
+            amd.calc_ref_path(px, py, 0.0, 0.0, 1.0, dt, 0.1, 10)
+    for v_ref, res in ((-1.0, 0.1), (1.0, -0.1), (float("nan"), 0.1), (1.0, 0.0), (1e308, 1e-308)):
+        with pytest.raises(amd.controller.MPPIError):
+            amd.calc_ref_path(px, py, 0.0, 0.0, v_ref, 0.1, res, 10)
+    idx, xr, yr, yaw = amd.calc_ref_path(px, py, 0.0, 0.0, 0.0, 0.1, 0.1, 10)   # v_ref = 0: stride 0, every point the same
+    assert idx == 0 and np.all(xr == px[0])
 
 
 @pytest.mark.parametrize("model,n", [("diff_drive", 3), ("steering_diff_drive", 3), ("full_body", 5)])
@@ -50,3 +61,10 @@ def test_plant_step_matches_predict_next_state(model, n):
         np.testing.assert_allclose(amd.plant_step(model, s, u, 0.1), helpers.plant(model, s, u, 0.1), rtol=0, atol=1e-15)
     with pytest.raises(amd.controller.MPPIError):
         amd.plant_step(model, np.array([0.0, 0.0, 2.0e5, 0.0, 0.0][:n]), np.zeros(5), 0.1)   # outside the specified range
+    # angles that leave +-1e4 rad are taken modulo 2 pi (the node reads them from tf in [-pi, pi]); below, untouched
+    s = np.array([0.0, 0.0, 1.0e4 - 0.05, 0.0, 0.0][:n])
+    u = np.array([0.0, 1.0, 0.0, 0.0, 0.0])
+    s1 = amd.plant_step(model, s, u, 0.1)
+    assert abs(s1[2]) <= np.pi and abs(np.sin(s1[2]) - np.sin(1.0e4 + 0.05)) < 1e-11 and abs(np.cos(s1[2]) - np.cos(1.0e4 + 0.05)) < 1e-11
+    s2 = amd.plant_step(model, s, -u, 0.1)
+    assert s2[2] == s[2] - 1.0 * 0.1
