@@ -87,15 +87,26 @@ def script_inputs(amd, w, n):
     return out
 
 
-def cpu_baseline(w, budget_s=12.0):
+def host_cores():
+    """CPUs this process may run on (the GPU boxes give a one-GPU job a share of a 256-CPU host)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(w, budget_s=12.0, by_value=False):
     """The oracle (CPU restatement of the reference's single-threaded loop, mt19937 mode) on a bounded sample of the
-    same workload: whole iterations of the full K until ~budget_s of CPU time is spent."""
+    same workload: whole iterations of the full K until ~budget_s of CPU time is spent.  by_value: calc_Cost /
+    calc_MinDistance take their arguments by value as the reference's signatures do (dd.h:130,140, dd:183,194; SURVEY.md
+    Q16) -- the reference-shaped baseline of SURVEY.md 8(d)(i); otherwise the same loop without those copies (a fast port)."""
     import ccv_mppi_path_tracker_amd as amd
     from oracle import oracle_lib as O
     p = w.params
     o = O.Oracle(p.model, p.num_samples, p.horizon, p.control_noise, p.lam, p.v_ref, p.u_min, p.u_max,
                  path_weight=p.path_weight, v_weight=p.v_weight, zmp_weight=p.zmp_weight, roll_v_weight=p.roll_v_weight,
                  back_weight=p.back_weight, yaw_weight=p.yaw_weight, roll_off=p.roll_off, steer_off=p.steer_off)
+    o.set_by_value(by_value)
     inputs = script_inputs(amd, w, 16)
     n, t0 = 0, time.perf_counter()
     while True:
@@ -105,10 +116,12 @@ def cpu_baseline(w, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 64:
             break
+    shape = ("AoS of std::vector, calc_Cost / calc_MinDistance arguments BY VALUE as dd.h:130,140" if by_value
+             else "the same loop without the reference's by-value copies: a fast port")
     return {"value": p.num_samples * n / el, "unit": "rollouts/s", "cores": 1, "kind": "port",
-            "sample": "%d whole iterations of %s (oracle/mppi_oracle.cpp, serial mt19937 like the reference, "
-                      "%.1f s, %.0f ms/iteration)" % (n, w.description, el, 1e3 * el / n),
-            "host_cpus": os.cpu_count()}
+            "sample": "%d whole iterations of %s (oracle/mppi_oracle.cpp, serial mt19937 like the reference; %s; "
+                      "%.1f s, %.0f ms/iteration)" % (n, w.description, shape, el, 1e3 * el / n),
+            "host_cpus": os.cpu_count(), "cores_available": host_cores()}
 
 
 def cpu_baseline_threads(w, threads, budget_s=6.0):
@@ -142,7 +155,36 @@ def cpu_baseline_threads(w, threads, budget_s=6.0):
     return {"value": k_t * threads * n / el, "unit": "rollouts/s", "cores": threads, "kind": "port",
             "sample": "%d whole iterations of %s, K sharded over %d threads (oracle/mppi_oracle.cpp, Philox mode, "
                       "%.1f s, %.1f ms/iteration)" % (n, w.description, threads, el, 1e3 * el / n),
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "cores_available": host_cores()}
+
+
+def closed_loop_leg(amd, torch, ctl, w, seed, warm=64, ticks=512):
+    """SURVEY.md 8(d) asks for the closed loop: the device-resident tick (plant + get_CurrentIndex + calc_RefPath +
+    iteration, three launches, no host data: ccv_mppi_resident_step_enqueue), `ticks` of them back to back after `warm`,
+    pose fed back every tick, on the workload's own path with the course extended so that it does not end."""
+    p = w.params
+    need = (warm + ticks + 8) * max(abs(p.u_max[0]), abs(p.u_min[0])) * p.dt + 2.0 * p.horizon * p.v_ref * p.dt
+    px, py = amd.make_path(w.path, p.resolution, length=max(need, 10.0))
+    s0 = np.zeros(p.nstate)
+    s0[0], s0[1] = px[0], py[0]
+    ctl.set_nominal(np.zeros((p.horizon - 1, p.udim)))
+    ctl.resident_set_path(px, py)
+    ctl.resident_set_pose(s0)
+    for i in range(warm):
+        ctl.resident_step_enqueue(p.dt, seed, i, advance=i > 0)
+    ctl.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(ticks):
+        ctl.resident_step_enqueue(p.dt, seed, warm + i, advance=True)
+    ctl.synchronize()
+    el = time.perf_counter() - t0
+    tr = ctl.resident_read_trace(max_rows=ticks)
+    d = np.hypot(px[None, :] - tr[:, 0:1], py[None, :] - tr[:, 1:2]).min(axis=1)
+    return {"us_per_tick": 1e6 * el / ticks, "rollouts_per_s": p.num_samples * ticks / el, "ticks": ticks, "warmup_ticks": warm,
+            "what": "device-resident closed loop: pose advanced by u*[0], window rebuilt on the device, %d path poses" % len(px),
+            "path_error_rms_m": float(np.sqrt(np.mean(d * d))), "path_error_max_m": float(d.max()),
+            "distance_travelled_m": float(np.hypot(np.diff(tr[:, 0]), np.diff(tr[:, 1])).sum())}
 
 
 def latest_pmc_traffic(workload_name):
@@ -174,6 +216,7 @@ def main():
                          "kernel (one node); rccl: one all-reduce per iteration; auto: p2p when it can be set up and "
                          "reproduces the all-reduce result, else rccl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-closed-loop-leg", action="store_true", help="skip the device-resident closed-loop figure of the default line")
     ap.add_argument("--no-state-store", action="store_true", help="skip the KxH x,y buffer (not the headline)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel hipEvents in the timed region")
     args = ap.parse_args()
@@ -224,7 +267,7 @@ def main():
     inputs = script_inputs(amd, w, 64)
     seed = 42
     # N > 1: per-GPU partials [sum w, sum w*u] -> one small RCCL all-reduce over xGMI -> every rank divides (no host sync)
-    driver, exchange_used = None, None
+    driver, exchange_used, exchange_info = None, None, {}
 
     def fence():
         if world > 1:
@@ -234,17 +277,30 @@ def main():
     if world > 1:
         rccl = sharded.ShardedMPPI(sharded.DevicePartials(ctl))
         driver, exchange_used = rccl, "rccl all-reduce"
+        zeros = np.zeros((p.horizon - 1, p.udim))
+
+        def run(drv, n):
+            for i in range(n):
+                s0, xr0, yr0, yaw00 = inputs[i % len(inputs)]
+                drv.iterate(s0, p.dt, xr0, yr0, yaw00, seed, i)
+
+        def time_256(drv):
+            """us per step of 256 steps after 1024 untimed ones (the first several hundred launches of a process are slow
+            on the host); the slowest rank decides"""
+            run(drv, 1024)
+            fence()
+            t_sel = time.perf_counter()
+            run(drv, 256)
+            fence()
+            t = torch.tensor([time.perf_counter() - t_sel], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item()) / 256 * 1e6
+
+        direct, good, xb = None, False, None
         if args.exchange != "rccl":
             xb = sharded.ExchangeBackend(ctl)
             good = xb.ok
             direct = sharded.ShardedMPPI(xb) if good else None
-            zeros = np.zeros((p.horizon - 1, p.udim))
-
-            def run(drv, n):
-                for i in range(n):
-                    s0, xr0, yr0, yaw00 = inputs[i % len(inputs)]
-                    drv.iterate(s0, p.dt, xr0, yr0, yaw00, seed, i)
-
             if good:
                 # both ways on the same inputs from the same warm start: the direct exchange is considered only if it
                 # reproduces the all-reduce result on every rank (rank-order vs ring-order sums: rounding only)
@@ -256,32 +312,31 @@ def main():
                 good = bool(np.all(np.isfinite(got[0])) and np.allclose(got[0], got[1], rtol=1e-9, atol=1e-12))
             flags = [None] * world
             dist.all_gather_object(flags, good)
-            if all(flags):
-                # ... and used only if it is also the faster one on this node (slowest rank decides)
-                took = []
-                for drv in (direct, rccl):
-                    run(drv, 1024)   # (the first several hundred launches of a process are slow on the host)
-                    fence()
-                    t_sel = time.perf_counter()
-                    run(drv, 256)
-                    fence()
-                    t = torch.tensor([time.perf_counter() - t_sel], dtype=torch.float64, device="cuda")
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    took.append(float(t.item()))
-                ctl.set_nominal(zeros)
-                if took[0] <= took[1] or args.exchange == "p2p":
-                    driver = direct
-                    exchange_used = "direct stores into the peers' HBM (hipIpc over xGMI), rank-order sum"
-                exchange_used += " [256 steps: direct %.1f us/step, rccl %.1f us/step]" % (took[0] / 256 * 1e6, took[1] / 256 * 1e6)
-            elif args.exchange == "p2p":
+            good = all(flags)
+            exchange_info.update(direct_available=bool(good), direct_fine_grained=bool(getattr(xb, "info", {}).get("fine_grained", False)))
+            if not good and args.exchange == "p2p":
                 print("bench.py: --exchange p2p could not be set up or verified: %s" % getattr(xb, "error", flags), file=sys.stderr)
                 sys.exit(5)
+        # the all-reduce path is always timed (north_star's figure), the direct exchange when it is available; the faster
+        # one runs the timed region unless --exchange forces one
+        ctl.set_nominal(zeros)
+        exchange_info.update(backend=backend, rccl_us_per_step=time_256(rccl))
+        if good:
+            ctl.set_nominal(zeros)
+            exchange_info.update(direct_us_per_step=time_256(direct))
+            if exchange_info["direct_us_per_step"] <= exchange_info["rccl_us_per_step"] or args.exchange == "p2p":
+                driver = direct
+                exchange_used = "direct stores into the peers' HBM (hipIpc over xGMI), rank-order sum"
+            exchange_used += " [256 steps: direct %.1f us/step, rccl %.1f us/step]" % (exchange_info["direct_us_per_step"],
+                                                                                       exchange_info["rccl_us_per_step"])
+        ctl.set_nominal(zeros)
     elif args.exchange == "p2p":   # N = 1: the exchange kernel talking to itself (its overhead over k_finalize)
         xb = sharded.ExchangeBackend(ctl)
         if not xb.ok:
             print("bench.py: --exchange p2p could not be set up: %s" % getattr(xb, "error", ""), file=sys.stderr)
             sys.exit(5)
         driver, exchange_used = sharded.ShardedMPPI(xb), "direct exchange, one rank"
+        exchange_info.update(direct_available=True, direct_fine_grained=bool(xb.info.get("fine_grained", False)))
 
     if args.closed_loop:
         if world > 1:
@@ -317,24 +372,33 @@ def main():
         if world > 1:
             fence()
     fence()
+    primed_iterations = n_prime
     if args.closed_loop:   # back to the start of the course (the set-up iterations above moved the robot)
         ctl.resident_set_pose(cl_start)
         ctl.set_nominal(np.zeros((p.horizon - 1, p.udim)))
     for i in range(args.warmup):
         step(i)
     fence()
-    # hipEvents around the rollout kernel and the whole launch sequence of every 8th step, on `stream` (recording on every
-    # step costs ~8 us/step of launch serialisation; the sampled launches are inside the timed region)
-    ctl.timing_enable(not args.no_kernel_events, every=8)
-    ctl.timing_read(reset=True)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    roll_us, iter_us, n_ev = ctl.timing_read(reset=True)
-    ctl.timing_enable(False)
+    # Kernel durations: a separate pass right after the timed region (same inputs, same warm start), hipEvents attached
+    # to the rollout kernel's dispatch and to the end of the launch sequence of EVERY launch, on `stream` -- at least 256
+    # launches whatever --steps is (recording inside the timed region would cost ~8 us/step of launch serialisation).
+    n_event_pass = 0 if args.no_kernel_events else max(256, min(args.steps, 2048))
+    roll_us = iter_us = 0.0
+    n_ev = 0
+    if n_event_pass:
+        ctl.timing_enable(True, every=1)
+        ctl.timing_read(reset=True)
+        for i in range(n_event_pass):
+            step(args.warmup + args.steps + i)
+        fence()
+        roll_us, iter_us, n_ev = ctl.timing_read(reset=True)
+        ctl.timing_enable(False)
     u_final = ctl.get_nominal()
     if not np.all(np.isfinite(u_final)):
         print("bench.py: non-finite controls after the timed region", file=sys.stderr)
@@ -360,9 +424,14 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            # the arithmetic is fp64 throughout (rollout, cost, exp, reductions); the N(0,1) variates are made in specified
+            # fp32 arithmetic from one 32-bit Philox word each (|z| <= 6.66, 2^-24 grid), then sigma * z + u* in fp64
+            "noise": "philox4x32-10 + fp32 Box-Muller (DESIGN.md section 3); the reference draws fp64 polar-method normals from mt19937",
+            "primed_iterations": primed_iterations,
             "config": {"workload": "%s: %s, u_dim=%d, launch parameters" % (w.name, w.description.replace(
                 "K=%d" % p.num_samples, "K=%d" % k_total), p.udim),
                        "samples_per_gpu": k_local, "horizon": p.horizon, "sharding": "K over %d GPU(s)" % world, **({"exchange": exchange_used} if exchange_used else {}),
+                       **({"exchange_detail": exchange_info} if exchange_info else {}),
                        "state_store": not args.no_state_store,
                        **({"closed_loop": "device-resident: plant + get_CurrentIndex + calc_RefPath on the device, "
                                           "%d path poses" % len(cl_px)} if args.closed_loop else {})},
@@ -370,6 +439,7 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": rollout_kernel_name(p.model, k_local, local_rank),
                          "kernel_avg_us": 1e6 * roll_avg_s,
+                         "kernel_launches_averaged": int(n_ev),
                          "algorithmic_bytes_per_launch": B_roll * k_local,
                          "iteration_avg_us": 1e6 * iter_avg_s,
                          "iteration_algorithmic_bytes": B * k_local,
@@ -403,10 +473,12 @@ def main():
             d = np.hypot(cl_px[None, :] - tr[:, 0:1], cl_py[None, :] - tr[:, 1:2]).min(axis=1)
             out["closed_loop"] = {"ticks": int(len(tr)), "distance_travelled_m": float(np.hypot(np.diff(tr[:, 0]), np.diff(tr[:, 1])).sum()),
                                   "path_error_rms_m": float(np.sqrt(np.mean(d * d))), "path_error_max_m": float(d.max())}
+        if world == 1 and not args.closed_loop and args.workload == "C2" and not args.no_closed_loop_leg:
+            out["closed_loop"] = closed_loop_leg(amd, torch, ctl, w, seed)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
-            # (the GPU boxes give a one-GPU job 16 host CPUs)
-            out["cpu_baseline_all_cores"] = cpu_baseline_threads(w, max(1, min(16, os.cpu_count() or 1)))
+            out["cpu_baseline_reference_shaped"] = cpu_baseline(w, budget_s=10.0, by_value=True)
+            out["cpu_baseline_all_cores"] = cpu_baseline_threads(w, max(1, host_cores()))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -5,6 +5,6 @@ this package is the thin Python host used by the tests and bench.py.  It never i
 """
 from . import capi, configs  # noqa: F401
 from .controller import MPPIController, calc_ref_path, make_path, plant_step  # noqa: F401
-from .node import ControllerNode  # noqa: F401
+from .node import ControllerNode, FullBodyStateEstimator  # noqa: F401
 
-__all__ = ["capi", "configs", "MPPIController", "ControllerNode", "calc_ref_path", "make_path", "plant_step"]
+__all__ = ["capi", "configs", "MPPIController", "ControllerNode", "FullBodyStateEstimator", "calc_ref_path", "make_path", "plant_step"]

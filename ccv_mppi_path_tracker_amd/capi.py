@@ -110,6 +110,17 @@ SIGNATURES = {
     "ccv_mppi_node_get_optimal": (C.c_int, [_H, _dp]),
     "ccv_mppi_node_get_ref_path": (C.c_int, [_H, _dp]),
     "ccv_mppi_node_get_optimal_path": (C.c_int, [_H, _dp]),
+    "ccv_mppi_node_fb_imu": (C.c_int, [_H, _dp, _dp, _dp, _dp]),
+    "ccv_mppi_node_fb_wrench": (C.c_int, [_H, C.c_int, _dp, _dp]),
+    "ccv_mppi_node_fb_pose": (C.c_int, [_H, C.c_double, C.c_double, C.c_double]),
+    "ccv_mppi_node_fb_update_state": (C.c_int, [_H, C.c_double]),
+    "ccv_mppi_node_fb_read": (C.c_int, [_H, _dp]),
+    "ccv_mppi_fb_estimator_create": (C.c_int, [C.POINTER(_H)]),
+    "ccv_mppi_fb_estimator_destroy": (C.c_int, [_H]),
+    "ccv_mppi_fb_estimator_imu": (C.c_int, [_H, _dp, _dp, _dp, _dp]),
+    "ccv_mppi_fb_estimator_wrench": (C.c_int, [_H, C.c_int, _dp, _dp]),
+    "ccv_mppi_fb_estimator_update": (C.c_int, [_H, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "ccv_mppi_fb_estimator_read": (C.c_int, [_H, _dp]),
 }
 
 _lib = None

@@ -86,6 +86,7 @@ void MPPIBase::publish_CmdVel() {
 bool MPPIBase::run_once(double dt) {
     if (!path_received_) return false;
     dt_ = dt;   // the reference overwrites dt_ with the measured loop period every pass (dd:346-348)
+    update_state();
     if (use_fused_ && device_prologue_) {
         // the window is built where it is used: pose in, one launch sequence, u* (and the window, for get_ref_path) out
         const double x0[5] = {current_state_.x, current_state_.y, current_state_.yaw, current_state_.roll, current_state_.pitch};
@@ -307,6 +308,145 @@ FullBodyMPPI::FullBodyMPPI(const ParamMap& p, int device) : MPPIBase(CCV_MPPI_FU
     create_handle(c);
 }
 
+// ---- full-body state estimator ------------------------------------------------------------------------------------
+// The arithmetic the reference delegates to tf and Eigen is written out: tf::Matrix3x3(q) (setRotation), getRPY()
+// (getEulerYPR, first solution), Matrix3x3 * Vector3 (tf LinearMath, ros/geometry noetic); Eigen cross / dot / +,- / scalar.
+namespace {
+constexpr double kMass = 60.0;                 // fb.h:216
+constexpr double kAlpha = 0.3;                 // fb.h:218: low-pass weight
+constexpr double kG = -9.81;                   // fb.h:32 (gravity compensation of the IMU acceleration)
+constexpr double kGravityZ = -9.8;             // fb.h:30 gravity_ (the ZMP model)
+// contactPositions (fb:57-63), in the order of force_sensor_topic_ (fb:49-56)
+constexpr double kContact[6][3] = {{0.0, 0.225, 0.075},    {0.0, -0.225, 0.075},   {0.245, 0.167, -0.003},
+                                   {0.245, -0.167, -0.004}, {-0.245, -0.167, -0.004}, {-0.245, 0.167, -0.003}};
+
+inline void cross3(const double a[3], const double b[3], double out[3]) {
+    out[0] = a[1] * b[2] - a[2] * b[1];
+    out[1] = a[2] * b[0] - a[0] * b[2];
+    out[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline void rotate3(const double m[9], const double v[3], double out[3]) {
+    for (int r = 0; r < 3; ++r) out[r] = m[3 * r] * v[0] + m[3 * r + 1] * v[1] + m[3 * r + 2] * v[2];
+}
+}  // namespace
+
+FullBodyStateEstimator::FullBodyStateEstimator() {
+    // fb.h:212-216, fb:86-91
+    const double upper_body_height = 0.8075, upper_body_depth = 0.208, upper_body_width = 0.208, mass = kMass;
+    base2CoM = upper_body_height / 2;
+    I_O[0] = (mass * (upper_body_width * upper_body_width + upper_body_height * upper_body_height)) / 12 + mass * base2CoM * base2CoM;
+    I_O[1] = (mass * (upper_body_height * upper_body_height + upper_body_depth * upper_body_depth)) / 12 + mass * base2CoM * base2CoM;
+    I_O[2] = (mass * (upper_body_depth * upper_body_depth + upper_body_width * upper_body_width)) / 12;
+}
+
+void FullBodyStateEstimator::imuCallback(const Imu& msg, const Rotation& imu_to_robot) {
+    for (int i = 0; i < 3; ++i) filterd_imu_angular_velocity_[i] = msg.angular_velocity[i];   // fb:209-211 (the filter is commented out)
+    // tf::Matrix3x3(imu_orientation_).getRPY(imu_roll_, imu_pitch_, imu_yaw_)  (fb:216-217)
+    const double qx = msg.orientation[0], qy = msg.orientation[1], qz = msg.orientation[2], qw = msg.orientation[3];
+    const double d = qx * qx + qy * qy + qz * qz + qw * qw;
+    const double s = 2.0 / d;
+    const double xs = qx * s, ys = qy * s, zs = qz * s;
+    const double wx = qw * xs, wy = qw * ys, wz = qw * zs;
+    const double xx = qx * xs, xy = qx * ys, xz = qx * zs;
+    const double yy = qy * ys, yz = qy * zs, zz = qz * zs;
+    const double r00 = 1.0 - (yy + zz), r10 = xy + wz, r20 = xz - wy, r21 = yz + wx, r22 = 1.0 - (xx + yy);
+    if (std::fabs(r20) >= 1.0) {   // pitch at +-90 degrees: yaw is taken as 0
+        imu_yaw_ = 0.0;
+        imu_roll_ = std::atan2(r21, r22);
+        imu_pitch_ = r20 < 0.0 ? M_PI / 2.0 : -M_PI / 2.0;
+    } else {
+        imu_pitch_ = -std::asin(r20);
+        const double cp = std::cos(imu_pitch_);
+        imu_roll_ = std::atan2(r21 / cp, r22 / cp);
+        imu_yaw_ = std::atan2(r10 / cp, r00 / cp);
+    }
+    double acc[3];
+    rotate3(imu_to_robot.m, msg.linear_acceleration, acc);   // fb:218-226
+    accel_x = acc[0];
+    accel_y = acc[1];
+    accel_z = acc[2];
+    accel_x -= kG * std::sin(imu_pitch_);                    // fb:233
+    imu_received_ = true;
+}
+
+void FullBodyStateEstimator::wrenchCallback(int sensor, const double force[3], const Rotation& wheel_to_robot) {
+    if (sensor < 0 || sensor >= 6) return;
+    if (sensor <= 1) rotate3(wheel_to_robot.m, force, force_sensor_data_[sensor]);   // fb:121-148
+    else for (int i = 0; i < 3; ++i) force_sensor_data_[sensor][i] = force[i];
+}
+
+void FullBodyStateEstimator::gazeboStatesCallback(double x, double y, double yaw) {
+    gazebo_pose_[0] = x;
+    gazebo_pose_[1] = y;
+    gazebo_pose_[2] = yaw;
+}
+
+bool FullBodyStateEstimator::calc_true_ZMP() {
+    double sumF[3] = {0.0, 0.0, 0.0}, sumM[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < 6; ++i) {
+        const double* f = force_sensor_data_[i];
+        if (f[2] > 0.0) {   // only sensors in contact (fb:580)
+            double m[3];
+            cross3(kContact[i], f, m);
+            for (int k = 0; k < 3; ++k) {
+                sumF[k] += f[k];
+                sumM[k] += m[k];
+            }
+        }
+    }
+    const double denom = (sumF[0] * 0.0 + sumF[1] * 0.0) + sumF[2] * 1.0;   // sumF.dot(n), n = (0, 0, 1)
+    if (std::fabs(denom) < 1e-6) return false;                            // fb:588-592
+    const double n[3] = {0.0, 0.0, 1.0};
+    double num[3];
+    cross3(n, sumM, num);
+    for (int k = 0; k < 3; ++k) true_ZMP[k] = kAlpha * (num[k] / denom) + (1 - kAlpha) * true_ZMP[k];   // fb:595
+    return true;
+}
+
+void FullBodyStateEstimator::computeZMPfromModel(const double CoM[3], const double accel[3], const double HGdot[3], double zmp[3]) const {
+    const double z[3] = {0.0, 0.0, 1.0};
+    const double mg[3] = {kMass * 0.0, kMass * 0.0, kMass * kGravityZ};
+    const double ma[3] = {kMass * accel[0], kMass * accel[1], kMass * accel[2]};
+    double c1[3], c2[3], M_O[3], num[3];
+    cross3(CoM, mg, c1);
+    cross3(CoM, ma, c2);
+    for (int k = 0; k < 3; ++k) M_O[k] = c1[k] - c2[k] - HGdot[k];
+    const double gd[3] = {0.0 - accel[0], 0.0 - accel[1], kGravityZ - accel[2]};
+    const double den = kMass * ((gd[0] * z[0] + gd[1] * z[1]) + gd[2] * z[2]);
+    cross3(z, M_O, num);
+    for (int k = 0; k < 3; ++k) zmp[k] = num[k] / den;
+}
+
+void FullBodyStateEstimator::get_CurrentState(double dt_) {
+    current_state_.x = gazebo_pose_[0];  // use_gazebo_pose_ (fb:546-550; the tf branch delivers the same three numbers)
+    current_state_.y = gazebo_pose_[1];
+    current_state_.yaw = gazebo_pose_[2];
+    current_state_.roll = imu_roll_;     // fb:552-553
+    current_state_.pitch = imu_pitch_;
+    const double CoM[3] = {base2CoM * std::sin(imu_pitch_), -base2CoM * std::sin(imu_roll_), base2CoM * std::cos(imu_pitch_) * std::cos(imu_roll_)};
+    const double accel[3] = {accel_x, accel_y, 0.0};
+    double H_G[3], H_Gdot[3], zmp[3];
+    for (int k = 0; k < 3; ++k) {
+        H_G[k] = I_O[k] * filterd_imu_angular_velocity_[k];   // I_O is diagonal (fb:87-91)
+        H_Gdot[k] = (H_G[k] - last_HG[k]) / dt_;
+        last_HG[k] = H_G[k];
+    }
+    computeZMPfromModel(CoM, accel, H_Gdot, zmp);
+    zmp_x_ = kAlpha * zmp[0] + (1 - kAlpha) * zmp_x_;   // fb:565-566
+    zmp_y_ = kAlpha * zmp[1] + (1 - kAlpha) * zmp_y_;
+}
+
+void FullBodyMPPI::get_CurrentState() {
+    est_.get_CurrentState(dt_);
+    current_state_ = est_.current_state_;
+}
+
+void FullBodyMPPI::update_state() {
+    if (!est_.imu_received_) return;   // (a caller that feeds set_CurrentState() directly keeps doing so)
+    est_.calc_true_ZMP();              // fb:623
+    get_CurrentState();                // fb:625
+}
+
 void FullBodyMPPI::publish_CmdPos() {
     const double v = optimal_solution[0], w = optimal_solution[1], direction = optimal_solution[2], roll_v = optimal_solution[3];
     if (steer_off_) {
@@ -431,6 +571,112 @@ int ccv_mppi_node_get_ref_path(ccv_mppi_node_t* node, double* out) {
         out[i * 3 + 1] = node->impl->y_ref_[i];
         out[i * 3 + 2] = node->impl->yaw_ref_[i];
     }
+    return CCV_MPPI_OK;
+}
+
+namespace {
+ccv_mppi_node::FullBodyMPPI* full_body(ccv_mppi_node_t* node) {
+    return node ? dynamic_cast<ccv_mppi_node::FullBodyMPPI*>(node->impl) : nullptr;
+}
+ccv_mppi_node::Rotation rotation_of(const double* basis9) {
+    ccv_mppi_node::Rotation r;
+    if (basis9) std::memcpy(r.m, basis9, sizeof(r.m));
+    return r;
+}
+void read_estimator(const ccv_mppi_node::FullBodyStateEstimator& est, const ccv_mppi_node::RobotState& st, double* out) {
+    out[0] = st.x; out[1] = st.y; out[2] = st.yaw; out[3] = st.roll; out[4] = st.pitch;
+    out[5] = est.zmp_x_; out[6] = est.zmp_y_;
+    for (int k = 0; k < 3; ++k) out[7 + k] = est.true_ZMP[k];
+    out[10] = est.imu_roll_; out[11] = est.imu_pitch_; out[12] = est.imu_yaw_;
+    out[13] = est.accel_x; out[14] = est.accel_y; out[15] = est.accel_z;
+}
+}  // namespace
+
+int ccv_mppi_node_fb_imu(ccv_mppi_node_t* node, const double* q, const double* w, const double* a, const double* basis9) {
+    ccv_mppi_node::FullBodyMPPI* fb = full_body(node);
+    if (!fb || !q || !w || !a) return CCV_MPPI_ERR_INVALID_ARG;
+    ccv_mppi_node::Imu m;
+    std::memcpy(m.orientation, q, sizeof(m.orientation));
+    std::memcpy(m.angular_velocity, w, sizeof(m.angular_velocity));
+    std::memcpy(m.linear_acceleration, a, sizeof(m.linear_acceleration));
+    fb->imuCallback(m, rotation_of(basis9));
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_node_fb_wrench(ccv_mppi_node_t* node, int sensor, const double* force3, const double* basis9) {
+    ccv_mppi_node::FullBodyMPPI* fb = full_body(node);
+    if (!fb || !force3 || sensor < 0 || sensor >= 6) return CCV_MPPI_ERR_INVALID_ARG;
+    fb->wrenchCallback(sensor, force3, rotation_of(basis9));
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_node_fb_pose(ccv_mppi_node_t* node, double x, double y, double yaw) {
+    ccv_mppi_node::FullBodyMPPI* fb = full_body(node);
+    if (!fb) return CCV_MPPI_ERR_INVALID_ARG;
+    fb->gazeboStatesCallback(x, y, yaw);
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_node_fb_update_state(ccv_mppi_node_t* node, double dt) {
+    ccv_mppi_node::FullBodyMPPI* fb = full_body(node);
+    if (!fb || !(dt == dt)) return CCV_MPPI_ERR_INVALID_ARG;
+    fb->set_dt(dt);
+    const bool ok = fb->calc_true_ZMP();
+    fb->get_CurrentState();
+    return ok ? 1 : 0;
+}
+
+int ccv_mppi_node_fb_read(ccv_mppi_node_t* node, double* out) {
+    ccv_mppi_node::FullBodyMPPI* fb = full_body(node);
+    if (!fb || !out) return CCV_MPPI_ERR_INVALID_ARG;
+    read_estimator(fb->estimator(), fb->current_state(), out);
+    return CCV_MPPI_OK;
+}
+
+// ---- the estimator on its own (no device) ----
+struct ccv_mppi_fb_estimator_t {
+    ccv_mppi_node::FullBodyStateEstimator impl;
+};
+
+int ccv_mppi_fb_estimator_create(ccv_mppi_fb_estimator_t** out) {
+    if (!out) return CCV_MPPI_ERR_INVALID_ARG;
+    *out = new (std::nothrow) ccv_mppi_fb_estimator_t();
+    return *out ? CCV_MPPI_OK : CCV_MPPI_ERR_ALLOC;
+}
+
+int ccv_mppi_fb_estimator_destroy(ccv_mppi_fb_estimator_t* e) {
+    if (!e) return CCV_MPPI_ERR_INVALID_ARG;
+    delete e;
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_fb_estimator_imu(ccv_mppi_fb_estimator_t* e, const double* q, const double* w, const double* a, const double* basis9) {
+    if (!e || !q || !w || !a) return CCV_MPPI_ERR_INVALID_ARG;
+    ccv_mppi_node::Imu m;
+    std::memcpy(m.orientation, q, sizeof(m.orientation));
+    std::memcpy(m.angular_velocity, w, sizeof(m.angular_velocity));
+    std::memcpy(m.linear_acceleration, a, sizeof(m.linear_acceleration));
+    e->impl.imuCallback(m, rotation_of(basis9));
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_fb_estimator_wrench(ccv_mppi_fb_estimator_t* e, int sensor, const double* force3, const double* basis9) {
+    if (!e || !force3 || sensor < 0 || sensor >= 6) return CCV_MPPI_ERR_INVALID_ARG;
+    e->impl.wrenchCallback(sensor, force3, rotation_of(basis9));
+    return CCV_MPPI_OK;
+}
+
+int ccv_mppi_fb_estimator_update(ccv_mppi_fb_estimator_t* e, double x, double y, double yaw, double dt) {
+    if (!e || !(dt == dt)) return CCV_MPPI_ERR_INVALID_ARG;
+    e->impl.gazeboStatesCallback(x, y, yaw);
+    const bool ok = e->impl.calc_true_ZMP();   // fb:623
+    e->impl.get_CurrentState(dt);              // fb:625
+    return ok ? 1 : 0;
+}
+
+int ccv_mppi_fb_estimator_read(ccv_mppi_fb_estimator_t* e, double* out) {
+    if (!e || !out) return CCV_MPPI_ERR_INVALID_ARG;
+    read_estimator(e->impl, e->impl.current_state_, out);
     return CCV_MPPI_OK;
 }
 

@@ -76,3 +76,70 @@ class ControllerNode:
         out = np.zeros((self.H - 1, 3))
         self.lib.ccv_mppi_node_get_optimal_path(self._h, capi.dptr(out))
         return out
+
+    # ---- full-body state estimator (fb:115-156,188-237,528-596); full_body nodes only ----
+    def fb_imu(self, quat_xyzw, angular_velocity, linear_acceleration, basis=None):
+        b = None if basis is None else capi.as_f64(basis).reshape(9)
+        rc = self.lib.ccv_mppi_node_fb_imu(self._h, capi.dptr(capi.as_f64(quat_xyzw)), capi.dptr(capi.as_f64(angular_velocity)),
+                                           capi.dptr(capi.as_f64(linear_acceleration)), None if b is None else capi.dptr(b))
+        if rc != capi.OK:
+            raise MPPIError(rc, "fb_imu")
+
+    def fb_wrench(self, sensor, force, basis=None):
+        b = None if basis is None else capi.as_f64(basis).reshape(9)
+        rc = self.lib.ccv_mppi_node_fb_wrench(self._h, int(sensor), capi.dptr(capi.as_f64(force)), None if b is None else capi.dptr(b))
+        if rc != capi.OK:
+            raise MPPIError(rc, "fb_wrench")
+
+    def fb_pose(self, x, y, yaw):
+        rc = self.lib.ccv_mppi_node_fb_pose(self._h, float(x), float(y), float(yaw))
+        if rc != capi.OK:
+            raise MPPIError(rc, "fb_pose")
+
+    def fb_read(self):
+        """current_state_ (5), zmp_x, zmp_y, true_ZMP (3), imu roll / pitch / yaw, accel x / y / z"""
+        out = np.zeros(16)
+        rc = self.lib.ccv_mppi_node_fb_read(self._h, capi.dptr(out))
+        if rc != capi.OK:
+            raise MPPIError(rc, "fb_read")
+        return out
+
+
+class FullBodyStateEstimator:
+    """The estimator of FullBodyMPPI on its own (host only, no device): include/ccv_mppi_node.hpp."""
+
+    def __init__(self):
+        self.lib = capi.load()
+        self._h = capi._H()
+        rc = self.lib.ccv_mppi_fb_estimator_create(C.byref(self._h))
+        if rc != capi.OK:
+            raise MPPIError(rc, "ccv_mppi_fb_estimator_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.ccv_mppi_fb_estimator_destroy(self._h)
+            self._h = capi._H()
+
+    def imu(self, quat_xyzw, angular_velocity, linear_acceleration, basis=None):
+        b = None if basis is None else capi.as_f64(basis).reshape(9)
+        rc = self.lib.ccv_mppi_fb_estimator_imu(self._h, capi.dptr(capi.as_f64(quat_xyzw)), capi.dptr(capi.as_f64(angular_velocity)),
+                                                capi.dptr(capi.as_f64(linear_acceleration)), None if b is None else capi.dptr(b))
+        if rc != capi.OK:
+            raise MPPIError(rc, "estimator imu")
+
+    def wrench(self, sensor, force, basis=None):
+        b = None if basis is None else capi.as_f64(basis).reshape(9)
+        rc = self.lib.ccv_mppi_fb_estimator_wrench(self._h, int(sensor), capi.dptr(capi.as_f64(force)), None if b is None else capi.dptr(b))
+        if rc != capi.OK:
+            raise MPPIError(rc, "estimator wrench")
+
+    def update(self, x, y, yaw, dt):
+        rc = self.lib.ccv_mppi_fb_estimator_update(self._h, float(x), float(y), float(yaw), float(dt))
+        if rc < 0:
+            raise MPPIError(rc, "estimator update")
+        return rc
+
+    def read(self):
+        out = np.zeros(16)
+        self.lib.ccv_mppi_fb_estimator_read(self._h, capi.dptr(out))
+        return out

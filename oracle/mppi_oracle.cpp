@@ -62,8 +62,12 @@ struct RobotStates {
     }
 };
 
-// Minimal 3-vector with Eigen's evaluation order for the operations fb uses
-// (fb:475-483, fb:597-603): cross, dot, +, -, scalar*, /scalar.
+// Minimal 3-vector for the Eigen operations fb uses (fb:475-483, fb:597-603): cross, dot, +, -, scalar*, /scalar, all
+// coefficient-wise in the obvious order.  dot is the one reduction: Eigen (3.3.x, the system package of the reference's
+// Ubuntu 20.04 / Noetic; version unpinned, not vendored) sums a Vector3d product as (a0 b0 + a1 b1) + a2 b2 when the
+// redux is vectorised (x86-64: one SSE2 packet of two doubles, then the odd element) and as a0 b0 + (a1 b1 + a2 b2) in
+// a non-vectorised build.  The reference only ever dots with z = (0, 0, 1) (fb:590 `sumF.dot(n)`, fb:601), where two of
+// the three products are exact zeros and both orders give the same bits; the first order is written here.
 struct V3 {
     double x, y, z;
     V3 cross(const V3& b) const { return {y * b.z - z * b.y, z * b.x - x * b.z, x * b.y - y * b.x}; }
@@ -210,6 +214,41 @@ struct Oracle {
         return min_d;
     }
 
+    // The reference's signatures take their arguments BY VALUE: calc_Cost(RobotStates sample) copies the
+    // 5 (dd) / 6 (sd) / 12 (fb) heap vectors of a sample per call (dd.h:130, fb.h:151), and
+    // calc_MinDistance(double, double, std::vector<double> x_ref, std::vector<double> y_ref) copies the window twice per
+    // (sample, t) (dd.h:140, dd:183; fb:411 calls it twice per t).  Same values, the reference's memory behaviour: this is
+    // what bench.py times as the reference-shaped CPU baseline.  (noinline: the copies must really happen.)
+    bool by_value = false;
+    __attribute__((noinline)) double min_distance_by_value(double x, double y, std::vector<double> xr, std::vector<double> yr) const {
+        double min_d = 100.0;
+        for (int j = 0; j < c.H; ++j) {
+            const double d = std::sqrt(std::pow(x - xr[j], 2) + std::pow(y - yr[j], 2));
+            if (d < min_d) min_d = d;
+        }
+        return min_d;
+    }
+    __attribute__((noinline)) double calc_cost_by_value(RobotStates s) const {
+        double cost = 0.0;
+        if (c.model != FULLBODY) {
+            for (int t = 0; t < c.H; ++t) {
+                const double d = min_distance_by_value(s.x_[t], s.y_[t], x_ref, y_ref);
+                const double v_cost = (s.u_[0][t] - c.v_ref) * (s.u_[0][t] - c.v_ref);
+                cost += c.path_weight * d * d + c.v_weight * v_cost;
+            }
+            return cost;
+        }
+        cost += c.yaw_weight * (s.yaw_[0] - yaw_ref0) * (s.yaw_[0] - yaw_ref0);
+        for (int t = 0; t < c.H - 2; ++t) {
+            cost += c.path_weight * min_distance_by_value(s.x_[t], s.y_[t], x_ref, y_ref) * min_distance_by_value(s.x_[t], s.y_[t], x_ref, y_ref);
+            cost += c.v_weight * (s.u_[0][t] - c.v_ref) * (s.u_[0][t] - c.v_ref);
+            cost += c.zmp_weight * s.zmp_y_[t] * s.zmp_y_[t];
+            cost += c.roll_v_weight * (s.u_[3][t + 1] - s.u_[3][t]) * (s.u_[3][t + 1] - s.u_[3][t]);
+            if (s.u_[0][t] < 0.0) cost += c.back_weight * s.u_[0][t] * s.u_[0][t];
+        }
+        return cost;
+    }
+
     // dd:194-210, sd:210-226 (t runs to H-1 inclusive: Q1 phantom control) ; fb:404-424
     double calc_cost(const RobotStates& s) const {
         double cost = 0.0;
@@ -239,7 +278,7 @@ struct Oracle {
         yaw_ref0 = yaw0;
         double sum = 0.0;
         for (int i = 0; i < c.K; ++i) {
-            const double cost = calc_cost(sample[i]);
+            const double cost = by_value ? calc_cost_by_value(sample[i]) : calc_cost(sample[i]);
             costs[i] = cost;
             weights[i] = std::exp(-cost / c.lambda);
             sum += weights[i];
@@ -257,6 +296,125 @@ struct Oracle {
                 for (int i = 0; i < c.K; ++i) acc += weights[i] * sample[i].u_[d][t];
                 optimal.u_[d][t] = acc;
             }
+    }
+};
+
+
+// =============================================================================
+// Full-body state estimator: imuCallback fb:199-237, wrenchCallback fb:115-156, get_CurrentState
+// fb:528-567, calc_true_ZMP fb:569-596, constants fb:49-63, fb.h:30-32,205-226.  O(1) host math per tick.
+// Third-party pieces on this path that are ABSENT from /root/reference and restated from their published source (ros/geometry
+// `tf`, Noetic 1.13.x, include/tf/LinearMath/Matrix3x3.h and Quaternion.h -- version unpinned by the reference's package.xml):
+//   tf::Matrix3x3(const Quaternion&) -> setRotation():  d = |q|^2, s = 2/d, the nine products in its order
+//   tf::Matrix3x3::getRPY() -> getEulerYPR(yaw, pitch, roll, solution 1): pitch = -asin(m[2][0]) unless |m[2][0]| >= 1
+//   tf::Matrix3x3 * tf::Vector3: row dot products, each x*x' + y*y' + z*z' left to right
+//   tf::getYaw(): plumbing, the pose's yaw arrives as a number here
+// No fixture of the reference pins any of it: parity unpinned, like the rest of this file.
+// =============================================================================
+struct FbEstimator {
+    // fb.h:205-216, fb:86-91
+    double mass = 60.0, alpha = 0.3, g = -9.81;
+    double base2CoM, Ixx, Iyy, Izz;
+    V3 gravity{0.0, 0.0, -9.8};
+    // imuCallback outputs
+    double imu_roll = 0.0, imu_pitch = 0.0, imu_yaw = 0.0;
+    double accel_x = 0.0, accel_y = 0.0, accel_z = 0.0;
+    V3 ang_vel{0.0, 0.0, 0.0};
+    // force sensors, order of force_sensor_topic_ (fb:49-56) = order of contactPositions (fb:63)
+    V3 force[6] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    V3 contact[6] = {{0.0, 0.225, 0.075},    {0.0, -0.225, 0.075},   {0.245, 0.167, -0.003},
+                     {0.245, -0.167, -0.004}, {-0.245, -0.167, -0.004}, {-0.245, 0.167, -0.003}};   // fb:57-63
+    V3 last_HG{0.0, 0.0, 0.0}, true_ZMP{0.0, 0.0, 0.0};
+    double state[5] = {0, 0, 0, 0, 0}, zmp_x = 0.0, zmp_y = 0.0;   // current_state_ (fb:74-76)
+
+    FbEstimator() {
+        const double upper_body_height = 0.8075, upper_body_depth = 0.208, upper_body_width = 0.208;
+        base2CoM = upper_body_height / 2;
+        Ixx = (mass * (upper_body_width * upper_body_width + upper_body_height * upper_body_height)) / 12 + mass * base2CoM * base2CoM;
+        Iyy = (mass * (upper_body_height * upper_body_height + upper_body_depth * upper_body_depth)) / 12 + mass * base2CoM * base2CoM;
+        Izz = (mass * (upper_body_depth * upper_body_depth + upper_body_width * upper_body_width)) / 12;
+    }
+
+    static V3 rotate(const double* m, const V3& v) {   // tf::Matrix3x3 (row-major m[9]) * tf::Vector3
+        return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+    }
+
+    // fb:199-237.  basis: rotation ROBOT_FRAME <- IMU_FRAME (the tf lookup of fb:218), row-major
+    void imu(const double* q, const double* w, const double* a, const double* basis) {
+        ang_vel = {w[0], w[1], w[2]};
+        // tf::Matrix3x3(imu_orientation_).getRPY(imu_roll_, imu_pitch_, imu_yaw_)
+        const double x = q[0], y = q[1], z = q[2], ww = q[3];
+        const double d = x * x + y * y + z * z + ww * ww;
+        const double s = 2.0 / d;
+        const double xs = x * s, ys = y * s, zs = z * s;
+        const double wx = ww * xs, wy = ww * ys, wz = ww * zs;
+        const double xx = x * xs, xy = x * ys, xz = x * zs;
+        const double yy = y * ys, yz = y * zs, zz = z * zs;
+        const double m00 = 1.0 - (yy + zz), m10 = xy + wz, m20 = xz - wy, m21 = yz + wx, m22 = 1.0 - (xx + yy);
+        (void)wz;
+        if (std::fabs(m20) >= 1.0) {
+            imu_yaw = 0.0;
+            const double delta = std::atan2(m21, m22);
+            if (m20 < 0.0) { imu_pitch = M_PI / 2.0; imu_roll = delta; }
+            else { imu_pitch = -M_PI / 2.0; imu_roll = delta; }
+        } else {
+            imu_pitch = -std::asin(m20);
+            imu_roll = std::atan2(m21 / std::cos(imu_pitch), m22 / std::cos(imu_pitch));
+            imu_yaw = std::atan2(m10 / std::cos(imu_pitch), m00 / std::cos(imu_pitch));
+        }
+        const V3 acc = rotate(basis, V3{a[0], a[1], a[2]});   // fb:219-226
+        accel_x = acc.x;
+        accel_y = acc.y;
+        accel_z = acc.z;
+        accel_x -= g * std::sin(imu_pitch);   // fb:233
+    }
+
+    // fb:115-156: the two wheel sensors are rotated into the robot frame, the four caster sensors are taken as they are
+    void wrench(int idx, const double* f, const double* basis) {
+        V3 v{f[0], f[1], f[2]};
+        if ((idx == 0 || idx == 1) && basis) v = rotate(basis, v);
+        force[idx] = v;
+    }
+
+    // fb:569-596
+    int calc_true_zmp() {
+        const V3 n{0.0, 0.0, 1.0};
+        V3 sumF{0.0, 0.0, 0.0}, sumM{0.0, 0.0, 0.0};
+        for (int i = 0; i < 6; ++i) {
+            if (force[i].z > 0.0) {
+                sumF = sumF + force[i];
+                sumM = sumM + contact[i].cross(force[i]);
+            }
+        }
+        const double denom = sumF.dot(n);
+        if (std::fabs(denom) < 1e-6) return 0;   // "denom is too small": true_ZMP keeps its value
+        const V3 numerator = n.cross(sumM);
+        true_ZMP = alpha * (numerator / denom) + (1 - alpha) * true_ZMP;
+        return 1;
+    }
+
+    // fb:597-603
+    V3 zmp_from_model(const V3& CoM, const V3& accel, const V3& HGdot) const {
+        const V3 z{0.0, 0.0, 1.0};
+        const V3 M_O = CoM.cross(mass * gravity) - CoM.cross(mass * accel) - HGdot;
+        return z.cross(M_O) / (mass * (gravity - accel).dot(z));
+    }
+
+    // fb:528-567 (use_gazebo_pose_ / tf branch: the pose arrives as numbers)
+    void get_current_state(double px, double py, double yaw, double dt) {
+        state[0] = px;
+        state[1] = py;
+        state[2] = yaw;
+        state[3] = imu_roll;
+        state[4] = imu_pitch;
+        const V3 CoM{base2CoM * std::sin(imu_pitch), -base2CoM * std::sin(imu_roll), base2CoM * std::cos(imu_pitch) * std::cos(imu_roll)};
+        const V3 accel{accel_x, accel_y, 0.0};
+        const V3 H_G{Ixx * ang_vel.x, Iyy * ang_vel.y, Izz * ang_vel.z};
+        const V3 H_Gdot = (H_G - last_HG) / dt;
+        last_HG = H_G;
+        const V3 ZMP = zmp_from_model(CoM, accel, H_Gdot);
+        zmp_x = alpha * ZMP.x + (1 - alpha) * zmp_x;
+        zmp_y = alpha * ZMP.y + (1 - alpha) * zmp_y;
     }
 };
 
@@ -303,6 +461,8 @@ void orc_calc_weights(void* h, const double* xr, const double* yr, double yaw0) 
     static_cast<Oracle*>(h)->calc_weights(xr, yr, yaw0);
 }
 void orc_determine_optimal(void* h) { static_cast<Oracle*>(h)->determine_optimal(); }
+// 1: calc_Cost / calc_MinDistance take their arguments by value, as the reference's signatures do
+void orc_set_by_value(void* h, int on) { static_cast<Oracle*>(h)->by_value = on != 0; }
 void orc_get_costs(void* h, double* out) {
     Oracle* o = static_cast<Oracle*>(h);
     std::copy(o->costs.begin(), o->costs.end(), out);
@@ -387,6 +547,27 @@ int orc_path_dkan(double resolution, double* px, double* py, int cap) {
         }
     }
     return n;
+}
+
+// full-body estimator (fb:115-156,199-237,528-596)
+void* orc_fbest_create() { return new FbEstimator(); }
+void orc_fbest_destroy(void* h) { delete static_cast<FbEstimator*>(h); }
+void orc_fbest_imu(void* h, const double* quat_xyzw, const double* ang_vel, const double* lin_acc, const double* basis9) {
+    static_cast<FbEstimator*>(h)->imu(quat_xyzw, ang_vel, lin_acc, basis9);
+}
+void orc_fbest_wrench(void* h, int sensor, const double* force, const double* basis9) {
+    static_cast<FbEstimator*>(h)->wrench(sensor, force, basis9);
+}
+int orc_fbest_true_zmp(void* h) { return static_cast<FbEstimator*>(h)->calc_true_zmp(); }
+void orc_fbest_state(void* h, double x, double y, double yaw, double dt) { static_cast<FbEstimator*>(h)->get_current_state(x, y, yaw, dt); }
+// out: state (5), zmp_x, zmp_y, true_ZMP (3), imu rpy (3), accel (3)
+void orc_fbest_read(void* h, double* out16) {
+    const FbEstimator* e = static_cast<FbEstimator*>(h);
+    for (int i = 0; i < 5; ++i) out16[i] = e->state[i];
+    out16[5] = e->zmp_x; out16[6] = e->zmp_y;
+    out16[7] = e->true_ZMP.x; out16[8] = e->true_ZMP.y; out16[9] = e->true_ZMP.z;
+    out16[10] = e->imu_roll; out16[11] = e->imu_pitch; out16[12] = e->imu_yaw;
+    out16[13] = e->accel_x; out16[14] = e->accel_y; out16[15] = e->accel_z;
 }
 
 // noise-spec probes for tests

@@ -57,6 +57,15 @@ def lib():
         L.orc_predict_states.argtypes = [C.c_void_p, dp, C.c_double]
         L.orc_calc_weights.argtypes = [C.c_void_p, dp, dp, C.c_double]
         L.orc_determine_optimal.argtypes = [C.c_void_p]
+        L.orc_set_by_value.argtypes = [C.c_void_p, C.c_int]
+        L.orc_fbest_create.restype = C.c_void_p
+        L.orc_fbest_destroy.argtypes = [C.c_void_p]
+        L.orc_fbest_imu.argtypes = [C.c_void_p, dp, dp, dp, dp]
+        L.orc_fbest_wrench.argtypes = [C.c_void_p, C.c_int, dp, dp]
+        L.orc_fbest_true_zmp.argtypes = [C.c_void_p]
+        L.orc_fbest_true_zmp.restype = C.c_int
+        L.orc_fbest_state.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_fbest_read.argtypes = [C.c_void_p, dp]
         L.orc_get_sum_w.restype = C.c_double
         L.orc_get_sum_w.argtypes = [C.c_void_p]
         L.orc_get_states.argtypes = [C.c_void_p, C.c_int, dp]
@@ -107,6 +116,11 @@ class Oracle:
         if getattr(self, "_h", None):
             lib().orc_destroy(self._h)
             self._h = None
+
+    def set_by_value(self, on=True):
+        """calc_Cost / calc_MinDistance take their arguments by value, as the reference's signatures do (dd.h:130,140;
+        SURVEY.md Q16): the same values at the reference's memory behaviour (bench.py's reference-shaped CPU baseline)."""
+        lib().orc_set_by_value(self._h, 1 if on else 0)
 
     # --- nominal (optimal_solution) ---
     def set_nominal(self, u):
@@ -177,6 +191,38 @@ class Oracle:
         n = self.H if idx < 5 else self.H - 2
         out = np.empty((self.K, n))
         lib().orc_get_states(self._h, idx, _dp(out))
+        return out
+
+
+class FbEstimator:
+    """Restatement of the full-body state estimator: imuCallback fb:199-237, wrenchCallback fb:115-156,
+    calc_true_ZMP fb:569-596, get_CurrentState fb:528-567."""
+
+    def __init__(self):
+        self._h = C.c_void_p(lib().orc_fbest_create())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_fbest_destroy(self._h)
+            self._h = None
+
+    def imu(self, quat_xyzw, ang_vel, lin_acc, basis=None):
+        b = _f64(np.eye(3) if basis is None else basis).reshape(9)
+        lib().orc_fbest_imu(self._h, _dp(_f64(quat_xyzw)), _dp(_f64(ang_vel)), _dp(_f64(lin_acc)), _dp(b))
+
+    def wrench(self, sensor, force, basis=None):
+        b = _f64(np.eye(3) if basis is None else basis).reshape(9)
+        lib().orc_fbest_wrench(self._h, int(sensor), _dp(_f64(force)), _dp(b))
+
+    def update(self, x, y, yaw, dt):
+        """calc_true_ZMP() then get_CurrentState() as run() does (fb:623-625); returns 0 when the denominator was too small."""
+        ok = lib().orc_fbest_true_zmp(self._h)
+        lib().orc_fbest_state(self._h, float(x), float(y), float(yaw), float(dt))
+        return ok
+
+    def read(self):
+        out = np.zeros(16)
+        lib().orc_fbest_read(self._h, _dp(out))
         return out
 
 

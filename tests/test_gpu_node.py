@@ -156,3 +156,59 @@ def test_cmd_pos_post_processing():
     out = n.run_once(0.1)
     assert out["cmd_pos"][0] == 0.0 and out["cmd_pos"][1] == 0.0 and out["cmd_pos"][4] == 0.0
     assert np.all(n.optimal_solution()[:, 2] == 0.0)            # steer_off zeroes the direction samples (fb:517)
+
+
+def _quat_from_rpy(roll, pitch, yaw):   # tf::Quaternion::setRPY, (x, y, z, w)
+    cr, sr, cp, sp, cy, sy = np.cos(roll / 2), np.sin(roll / 2), np.cos(pitch / 2), np.sin(pitch / 2), np.cos(yaw / 2), np.sin(yaw / 2)
+    return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy])
+
+
+def test_full_body_loop_closed_through_the_state_estimator():
+    """the FullBodyMPPI mirror produces current_state_ itself.  The plant's pose reaches the node only as
+    sensor messages -- the Gazebo model pose, an IMU orientation / rates / acceleration, six force sensors -- and
+    run_once() does what run() does (fb:621-644): calc_true_ZMP(), get_CurrentState(), then the four hot methods.  The
+    oracle controller gets the same state through the oracle's restatement of the estimator; both loops must agree, and
+    the estimated roll / pitch must be the plant's."""
+    from oracle import oracle_lib as O
+    model, kind, over = CASES[2]
+    p = _oracle_params(model, over)
+    px, py = amd.make_path(kind)
+    node = ControllerNode(model, over, seed=7)
+    node.set_path(px, py)
+    o, est = helpers.oracle_for(p), O.FbEstimator()
+    s = np.zeros(p.nstate)
+    s[:5] = px[0], py[0], 0.0, 0.02, -0.01
+    u_prev = np.zeros(p.udim)
+    for it in range(15):
+        dt = 0.1
+        # sensors as a simulator would publish them from the plant state and the last command
+        q = _quat_from_rpy(s[3], s[4], s[2])
+        rates = [u_prev[3], u_prev[4], u_prev[1]]                       # roll, pitch, yaw rate
+        acc = [0.3 * np.cos(it), u_prev[0] * u_prev[1], 9.8]
+        load = 60.0 * 9.8 / 6.0
+        forces = [[0.0, 0.0, load * (1.0 + 0.2 * np.sin(0.3 * it + k))] for k in range(6)]
+        node.fb_imu(q, rates, acc)
+        est.imu(q, rates, acc)
+        for k in range(6):
+            node.fb_wrench(k, forces[k])
+            est.wrench(k, forces[k])
+        node.fb_pose(s[0], s[1], s[2])
+        out = node.run_once(dt)                                          # calc_true_ZMP + get_CurrentState + iteration
+        est.update(s[0], s[1], s[2], dt)
+        e_o, e_n = est.read(), node.fb_read()
+        np.testing.assert_array_equal(e_n, e_o)                          # estimator: host mirror == oracle restatement
+        np.testing.assert_allclose(e_n[:5], s, atol=1e-14)               # and it recovers the plant's pose and attitude
+        xr, yr, yaw = O_window(p, (px, py), e_o[:5], dt)
+        u_o = o.iterate(e_o[:5], dt, xr, yr, yaw[0], seed=7, rng="philox", iteration=it)
+        u_n = node.optimal_solution()
+        assert helpers.rel_err(u_n, u_o) < 1e-8
+        assert out["cmd_vel"] == (u_n[0, 0], u_n[0, 1])
+        roll_cmd = min(max(e_n[3] + u_n[0, 3] * dt, -30 * DEG), 30 * DEG)   # fb:266-269 from the ESTIMATED roll
+        assert abs(out["cmd_pos"][4] - roll_cmd) < 1e-15
+        o.set_nominal(u_n)
+        u_prev = u_n[0]
+        s = amd.plant_step(model, s, u_n[0], dt)
+    assert s[0] > px[0] + 1.0 and np.all(np.abs(e_n[7:9]) < 0.3)          # drove along the path; true ZMP inside the footprint
+    # a node of another model has no estimator
+    with pytest.raises(amd.controller.MPPIError):
+        ControllerNode("diff_drive", CASES[0][2]).fb_pose(0, 0, 0)
