@@ -276,7 +276,7 @@ def main():
 
     if world > 1:
         rccl = sharded.ShardedMPPI(sharded.DevicePartials(ctl))
-        driver, exchange_used = rccl, "rccl all-reduce"
+        driver, exchange_used = rccl, ("rccl all-reduce" if backend == "nccl" else "%s all-reduce (rehearsal, not RCCL)" % backend)
         zeros = np.zeros((p.horizon - 1, p.udim))
 
         def run(drv, n):
@@ -320,15 +320,17 @@ def main():
         # the all-reduce path is always timed (north_star's figure), the direct exchange when it is available; the faster
         # one runs the timed region unless --exchange forces one
         ctl.set_nominal(zeros)
-        exchange_info.update(backend=backend, rccl_us_per_step=time_256(rccl))
+        # (key name: `rccl_us_per_step` only when the process group really is RCCL; the one-device rehearsal uses gloo)
+        ar_key = "rccl_us_per_step" if backend == "nccl" else "%s_allreduce_us_per_step" % backend
+        exchange_info.update(backend=backend, **{ar_key: time_256(rccl)})
         if good:
             ctl.set_nominal(zeros)
             exchange_info.update(direct_us_per_step=time_256(direct))
-            if exchange_info["direct_us_per_step"] <= exchange_info["rccl_us_per_step"] or args.exchange == "p2p":
+            if exchange_info["direct_us_per_step"] <= exchange_info[ar_key] or args.exchange == "p2p":
                 driver = direct
                 exchange_used = "direct stores into the peers' HBM (hipIpc over xGMI), rank-order sum"
-            exchange_used += " [256 steps: direct %.1f us/step, rccl %.1f us/step]" % (exchange_info["direct_us_per_step"],
-                                                                                       exchange_info["rccl_us_per_step"])
+            exchange_used += " [256 steps: direct %.1f us/step, %s all-reduce %.1f us/step]" % (
+                exchange_info["direct_us_per_step"], "rccl" if backend == "nccl" else backend, exchange_info[ar_key])
         ctl.set_nominal(zeros)
     elif args.exchange == "p2p":   # N = 1: the exchange kernel talking to itself (its overhead over k_finalize)
         xb = sharded.ExchangeBackend(ctl)
