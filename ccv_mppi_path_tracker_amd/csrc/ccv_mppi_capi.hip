@@ -169,6 +169,7 @@ void fill_args(const ccv_mppi_handle* h, RolloutArgs& A, const double* x0, doubl
     A.fb_L = base2CoM;
     A.fb_Ixx = (mass * (upper_body_width * upper_body_width + upper_body_height * upper_body_height)) / 12 + mass * base2CoM * base2CoM;
     A.fb_gz = -9.8;  // fb.h:30
+    A.inv_dt = 1.0 / dt;
     A.seed_lo = (uint32_t)seed;
     A.seed_hi = (uint32_t)(seed >> 32);
     A.iter_lo = (uint32_t)iter;
@@ -296,6 +297,8 @@ bool fast_trig_safe(const ccv_mppi_handle* h, const RolloutArgs& A, int mode) {
         if (!(umax[1] * std::fabs(A.dt) <= kSmallTurnLimit) || !(umax[3] * std::fabs(A.dt) <= kSmallTurnLimit) ||
             !(umax[4] * std::fabs(A.dt) <= kSmallTurnLimit) || !(umax[2] <= kSmallTurnLimit))
             return false;
+        // ... and divides by dt through its reciprocal (div_uniform, mppi_kernels.h): nothing may overflow or vanish on the way
+        if (!(std::fabs(A.dt) >= 1.0e-100 && std::fabs(A.dt) <= 1.0e100) || !(umax[0] <= 1.0e100) || !(umax[3] <= 1.0e100)) return false;
     }
     return bound <= kFastTrigLimit;   // false for NaN
 }

@@ -63,6 +63,7 @@ struct RolloutArgs {
     double umin[5], umax[5];
     double w_path, w_v, w_zmp, w_rollv, w_back, w_yaw;
     double fb_mass, fb_L, fb_Ixx, fb_gz;  // fb.h:212-216, fb:86-91, fb.h:30
+    double inv_dt;                        // 1 / dt, correctly rounded on the host: div_uniform() below
     uint32_t seed_lo, seed_hi, iter_lo, iter_hi;
     int32_t K, pitch, H, k_offset;
     int32_t steer_off, store_u, store_xy, do_cost;
@@ -122,6 +123,19 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// x / d for a wave-uniform divisor d whose reciprocal r = RN(1 / d) was formed once: q = RN(x r), the exact remainder
+// x - q d by FMA, one correction -- the correctly rounded quotient (Markstein's theorem for a faithful q and a correctly
+// rounded r), in 3 instructions instead of the ~10 of an fp64 division.  The full-body ZMP term divides by dt twice per
+// sample-step (fb:469, fb:479-481).  (Its third division, by mass * gravity_.z (fb:601), stays a division: one more pair of
+// kernel-argument registers pushes the one-wave full-body kernel from 232 to 256 VGPRs with 17 spilled -- SGPR spills live
+// in VGPR lanes -- and costs more than the division: C4 287 -> 294 us, measured.)  Valid while nothing overflows or
+// vanishes on the way (the host admits the kernels that use it only for 1e-100 <= |dt| <= 1e100 and control bounds below
+// 1e100, fast_trig_safe(); anything else runs the plain kernel with true divisions); a zero quotient may lose its sign.
+__device__ __forceinline__ double div_uniform(const double x, const double d, const double r) {
+    const double q = x * r;
+    return fma(fma(-q, d, x), r, q);
 }
 
 // dd:62-67

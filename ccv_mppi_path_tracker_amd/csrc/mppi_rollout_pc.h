@@ -213,9 +213,9 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
                         }
                         if (t >= 1) {   // finish index t-1 <= H-3: ZMP (fb:468-485, 597-603) and roll-rate terms
                             const double mgz = A.fb_mass * A.fb_gz;                               // (mass*gravity_).z
-                            const double drive_accel = (u[0] - S.p_v) / dt;                       // fb:469
+                            const double drive_accel = div_uniform(u[0] - S.p_v, dt, A.inv_dt);   // fb:469
                             const double ay = drive_accel * S.p_sdir + S.p_ac * S.p_cdir;         // fb:473
-                            const double hgdot_x = (A.fb_Ixx * u[3] - A.fb_Ixx * S.p_rv) / dt;    // fb:479-481
+                            const double hgdot_x = div_uniform(A.fb_Ixx * u[3] - A.fb_Ixx * S.p_rv, dt, A.inv_dt);   // fb:479-481
                             const double mo_x = (S.p_c2 * mgz + S.p_c3 * (A.fb_mass * ay)) - hgdot_x;  // fb:600
                             const double zmp_y = mo_x / mgz;                                      // fb:601 (accel.z == 0)
                             cost += A.w_zmp * zmp_y * zmp_y;                                      // fb:416
@@ -536,9 +536,9 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
                     cost += (in && u[tt][0] < 0.0) ? cb : 0.0;
                 }
                 {   // t >= 1: finish index t-1: ZMP (fb:468-485, 597-603) and roll-rate terms
-                    const double drive_accel = (u[tt][0] - S.p_v) / dt;                          // fb:469
+                    const double drive_accel = div_uniform(u[tt][0] - S.p_v, dt, A.inv_dt);      // fb:469
                     const double ay = drive_accel * S.p_sdir + S.p_ac * S.p_cdir;                // fb:473
-                    const double hgdot_x = (A.fb_Ixx * u[tt][3] - A.fb_Ixx * S.p_rv) / dt;       // fb:479-481
+                    const double hgdot_x = div_uniform(A.fb_Ixx * u[tt][3] - A.fb_Ixx * S.p_rv, dt, A.inv_dt);   // fb:479-481
                     const double mo_x = (S.p_c2 * mgz + S.p_c3 * (A.fb_mass * ay)) - hgdot_x;    // fb:600
                     const double zmp_y = mo_x / mgz;                                             // fb:601
                     const double cz = A.w_zmp * zmp_y * zmp_y;                                   // fb:416
