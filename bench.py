@@ -208,6 +208,9 @@ def main():
     ap.add_argument("--workload", default="C2", help="C2 (headline) | C3 | C4")
     ap.add_argument("--samples-per-gpu", type=int, default=None)
     ap.add_argument("--path", default=None, help="reference path instead of the workload's: straight | sinusoid | dkan")
+    ap.add_argument("--dt", type=float, default=None,
+                    help="loop period instead of the workload's 0.1 s (the node measures it, dd:346-348): beyond |w|max*dt = pi/4 "
+                         "(0.3927 s at the C2 limits) the host routes the call to the plain kernel (not the headline)")
     ap.add_argument("--closed-loop", action="store_true",
                     help="not the headline: the device-resident closed loop (pose advanced by u*[0] and the window rebuilt "
                          "on the device every step; the workload's path generator with the course extended so that it never ends)")
@@ -254,6 +257,9 @@ def main():
     if args.path:
         import dataclasses
         w = dataclasses.replace(w, path=args.path, description=w.description.replace(w.path, args.path))
+    if args.dt is not None:
+        import dataclasses
+        w = dataclasses.replace(w, params=w.params.with_(dt=args.dt), description=w.description + " dt=%g" % args.dt)
     p = w.params
     k_local = args.samples_per_gpu or p.num_samples
     k_total = k_local * world
@@ -439,7 +445,8 @@ def main():
                                           "%d path poses" % len(cl_px)} if args.closed_loop else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": rollout_kernel_name(p.model, k_local, local_rank),
+                         "kernel": rollout_kernel_name(p.model, k_local, local_rank) if args.dt is None else
+                                   rollout_kernel_name(p.model, k_local, local_rank) + " (or k_rollout_cost beyond the small-turn gate)",
                          "kernel_avg_us": 1e6 * roll_avg_s,
                          "kernel_launches_averaged": int(n_ev),
                          "algorithmic_bytes_per_launch": B_roll * k_local,

@@ -386,6 +386,35 @@ def test_diff_drive_turn_per_step_gate(dt):
     np.testing.assert_allclose(g.read_candidates(), xs_o, rtol=1e-11, atol=1e-11)
 
 
+def test_measured_dt_across_the_small_turn_gate(monkeypatch):
+    """The node takes dt from its clock (dd:346-348), so one slow tick can cross |w|max * dt = pi/4 (0.3927 s at w_max = 2)
+    and change kernels: the rotation-based production kernel below, the plain kernel with OCML's sincos above
+    (fast_trig_safe, ccv_mppi_capi.hip).  Loop periods drawn around the gate: whatever the host picks must agree with the
+    plain kernel forced (CCV_MPPI_KERNEL=v1) and with the oracle, with no jump at the switch; the warm start carries
+    over from one period to the next as it would in the node."""
+    p0 = configs.diff_drive_defaults(640, 50)
+    path = helpers.oracle_path("sinusoid")
+    state = start_state(p0, path)
+    gate = np.pi / 4 / 2.0
+    dts = [gate * f for f in (0.97, 0.999, 0.9999999, 1.0, 1.0000001, 1.001, 1.03)] + [0.39, 0.1, 0.41, 0.1]
+    g = MPPIController(p0)
+    monkeypatch.setenv("CCV_MPPI_KERNEL", "v1")
+    ref = MPPIController(p0)
+    o = helpers.oracle_for(p0)
+    for it, dt in enumerate(dts):
+        p = p0.with_(dt=dt)
+        xr, yr, yaw = helpers.oracle_window(p, path, state)
+        u_g = g.iterate(state, dt, xr, yr, yaw[0], 8, it, want_stats=False)
+        u_r = ref.iterate(state, dt, xr, yr, yaw[0], 8, it, want_stats=False)
+        u_o = o.iterate(state, dt, xr, yr, yaw[0], seed=8, rng="philox", iteration=it)
+        np.testing.assert_array_equal(g.read_controls(), ref.read_controls())
+        np.testing.assert_allclose(g.read_costs(), ref.read_costs(), rtol=1e-11)
+        assert np.max(np.abs(g.read_costs() - o.costs()) / o.costs()) < TOL_COST
+        assert helpers.rel_err(u_g, u_r) < 1e-9 and helpers.rel_err(u_g, u_o) < 1e-8
+        ref.set_nominal(u_g)
+        o.set_nominal(u_g)
+
+
 @pytest.mark.parametrize("case", ["launch", "dt_0.7", "dt_1.0", "wide_direction", "fast_roll"])
 def test_full_body_small_angle_gates(case):
     """Full body evaluates sin / cos of yaw, roll and pitch once per block of 8 steps and advances them by rotations with

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-L=$GRAFT_REPO_ROOT/_abl
-BENCH_ARGS="--workload C4 --steps 100 --warmup 10 --no-cpu-baseline" bash tools/ab_bench.sh r02c_stag 2 -- "new=X=1" "stag2=CCV_MPPI_LIB=$L/lib_stag2.so" "stag4=CCV_MPPI_LIB=$L/lib_stag4.so" "stag8=CCV_MPPI_LIB=$L/lib_stag8.so"
-BENCH_ARGS="--samples-per-gpu 131072 --steps 100 --warmup 10 --no-cpu-baseline" bash tools/ab_bench.sh r02c_stag_dd 2 -- "new=X=1" "stag2=CCV_MPPI_LIB=$L/lib_stag2.so" "stag4=CCV_MPPI_LIB=$L/lib_stag4.so"
+mkdir -p gpurun_out/r02e
+./tools/microbench/dist_loop > gpurun_out/r02e/dist_loop.txt 2>&1
+grep -v "^$" gpurun_out/r02e/dist_loop.txt | grep "V7\|V8\|V9\|V10\|V6"
+for k in pc solo; do CCV_MPPI_KERNEL=$k python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-closed-loop-leg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$k', d['roofline']['kernel_avg_us'], 1e3*d['ms_per_step'])"; done

@@ -145,6 +145,99 @@ __device__ __forceinline__ void v7(const double (&px)[TU], const double (&py)[TU
     }
 }
 
+// ---- fp32 SCREEN forms: what a screening pass over the same pairs costs before any refinement ----
+// V8: 2 v_fma_f32 + 1 v_min_f32 per pair, 4 points per group (the minimum an fp32 screen can be)
+// V9: the same with packed math: two states per v_pk_fma_f32
+// V10: V8 + the cheapest bookkeeping that lets a refinement find its candidates: per group of 4 points and state the
+//      group minimum, a compare, a select of the group index, and the runner-up group minimum (med3) to validate it
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void v8(const float (&px)[TU], const float (&py)[TU], float (&m)[TU], int H, const float2* sab, const float* sc) {
+    const int H4 = (H + 3) & ~3;
+    for (int j = 0; j < H4; j += 4) {
+        float2 ab[4]; float c[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { ab[jj] = sab[j + jj]; c[jj] = sc[j + jj]; }
+#pragma unroll
+        for (int i = 0; i < TU; ++i) {
+            float f[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) f[jj] = __builtin_fmaf(ab[jj].x, px[i], __builtin_fmaf(ab[jj].y, py[i], c[jj]));
+            const float t = fminf(fminf(f[0], f[1]), fminf(f[2], f[3]));
+            asm("v_min_f32 %0, %1, %2" : "=v"(m[i]) : "v"(m[i]), "v"(t));
+        }
+    }
+}
+__device__ __forceinline__ void v9(const float (&px)[TU], const float (&py)[TU], float (&m)[TU], int H, const float2* sab, const float* sc) {
+    const int H4 = (H + 3) & ~3;
+    f32x2 qx[TU / 2], qy[TU / 2];
+#pragma unroll
+    for (int i = 0; i < TU / 2; ++i) { qx[i] = f32x2{px[2 * i], px[2 * i + 1]}; qy[i] = f32x2{py[2 * i], py[2 * i + 1]}; }
+    for (int j = 0; j < H4; j += 4) {
+        float2 ab[4]; float c[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { ab[jj] = sab[j + jj]; c[jj] = sc[j + jj]; }
+#pragma unroll
+        for (int i = 0; i < TU / 2; ++i) {
+            f32x2 f[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x2 a2{ab[jj].x, ab[jj].x}, b2{ab[jj].y, ab[jj].y}, c2{c[jj], c[jj]};
+                f[jj] = __builtin_elementwise_fma(a2, qx[i], __builtin_elementwise_fma(b2, qy[i], c2));
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float t = fminf(fminf(f[0][h], f[1][h]), fminf(f[2][h], f[3][h]));
+                asm("v_min_f32 %0, %1, %2" : "=v"(m[2 * i + h]) : "v"(m[2 * i + h]), "v"(t));
+            }
+        }
+    }
+}
+__device__ __forceinline__ void v10(const float (&px)[TU], const float (&py)[TU], float (&m)[TU], float (&m2)[TU], int (&g)[TU], int H,
+                                    const float2* sab, const float* sc) {
+    const int H4 = (H + 3) & ~3;
+    for (int j = 0; j < H4; j += 4) {
+        float2 ab[4]; float c[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { ab[jj] = sab[j + jj]; c[jj] = sc[j + jj]; }
+#pragma unroll
+        for (int i = 0; i < TU; ++i) {
+            float f[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) f[jj] = __builtin_fmaf(ab[jj].x, px[i], __builtin_fmaf(ab[jj].y, py[i], c[jj]));
+            const float t = fminf(fminf(f[0], f[1]), fminf(f[2], f[3]));
+            g[i] = t < m[i] ? j : g[i];
+            m2[i] = __builtin_amdgcn_fmed3f(t, m[i], m2[i]);
+            asm("v_min_f32 %0, %1, %2" : "=v"(m[i]) : "v"(m[i]), "v"(t));
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k32(double* out, int H, unsigned long long* cyc, const Win W) {
+    __shared__ float2 sab[MAXH];
+    __shared__ float sc[MAXH];
+    for (int j = threadIdx.x; j < H + 8; j += 256) { sab[j] = make_float2((float)W.a[j], (float)W.b[j]); sc[j] = (float)W.c[j]; }
+    __syncthreads();
+    float px[TU], py[TU], m[TU], m2[TU];
+    int g[TU];
+#pragma unroll
+    for (int i = 0; i < TU; ++i) { px[i] = 0.01f * threadIdx.x + i; py[i] = 0.02f * threadIdx.x - i; m[i] = 1e30f; m2[i] = 1e30f; g[i] = 0; }
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < REP; ++r) {
+        if (V == 8) v8(px, py, m, H, sab, sc);
+        else if (V == 9) v9(px, py, m, H, sab, sc);
+        else v10(px, py, m, m2, g, H, sab, sc);
+#pragma unroll
+        for (int i = 0; i < TU; ++i) px[i] += 1e-9f * m[i];
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < TU; ++i) s += m[i] + m2[i] + g[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void k(double* out, int H, unsigned long long* cyc, const Win W) {
     __shared__ double2 sab[MAXH];
@@ -177,16 +270,21 @@ __global__ __launch_bounds__(256) void k(double* out, int H, unsigned long long*
 
 template <int V>
 void run(const char* name, int wps, int H, const Win& W) {
+    constexpr bool F32 = V >= 8;
     const int blocks = 256 * wps;
     double* out; unsigned long long* cyc;
     CHECK(hipMalloc(&out, sizeof(double) * blocks * 256));
     CHECK(hipMalloc(&cyc, 8));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, out, H, cyc, W);
+    auto launch = [&]() {
+        if constexpr (F32) hipLaunchKernelGGL(k32<V>, dim3(blocks), dim3(256), 0, 0, out, H, cyc, W);
+        else hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, out, H, cyc, W);
+    };
+    for (int w = 0; w < 2; ++w) launch();
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
     const int reps = 5;
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, out, H, cyc, W);
+    for (int r = 0; r < reps; ++r) launch();
     CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long hc; CHECK(hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost));
@@ -201,7 +299,7 @@ int main() {
     Win W;
     for (int j = 0; j < MAXH; ++j) { W.a[j] = -2.0 * 0.12 * j; W.b[j] = 0.3 * j; W.c[j] = 0.01 * j * j; }
     const int H = 50;
-    for (int wps : {1, 2, 4}) {
+    for (int wps : {1, 2, 3, 4}) {
         run<0>("V0 fmin, load-at-use", wps, H, W);
         run<4>("V4 fmin, unroll 4", wps, H, W);
         run<1>("V1 asm min + rotate", wps, H, W);
@@ -210,6 +308,9 @@ int main() {
         run<5>("V5 asm block/pt", wps, H, W);
         run<7>("V7 fmin, 4/grp, ping-pong", wps, H, W);
         run<6>("V6 asm block, 2 pts/iter", wps, H, W);
+        run<8>("V8 fp32 screen", wps, H, W);
+        run<9>("V9 fp32 screen, packed", wps, H, W);
+        run<10>("V10 fp32 screen + group idx", wps, H, W);
         printf("\n");
     }
     return 0;

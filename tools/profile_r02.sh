@@ -14,6 +14,9 @@ python3 $R/bench.py --workload C3 --steps 100 --warmup 10 --no-cpu-baseline > $O
 python3 $R/bench.py --workload C4 --steps 100 --warmup 10 --no-cpu-baseline > $O/C4_bench.json 2>/dev/null
 python3 $R/bench.py --samples-per-gpu 524288 --steps 60 --warmup 10 --no-cpu-baseline > $O/c2_K524288_bench.json 2>/dev/null
 python3 $R/bench.py --path straight --steps 200 --warmup 20 --no-cpu-baseline > $O/c2_straight_bench.json 2>/dev/null
+# the plain kernel the host falls back to when a measured loop period crosses |w|max dt = pi/4 (C2 limits: 0.3927 s)
+python3 $R/bench.py --dt 0.41 --steps 200 --warmup 20 --no-cpu-baseline --no-closed-loop-leg > $O/c2_dt0.41_fallback_bench.json 2>/dev/null
+python3 $R/bench.py --dt 0.39 --steps 200 --warmup 20 --no-cpu-baseline --no-closed-loop-leg > $O/c2_dt0.39_bench.json 2>/dev/null
 echo "bench lines done"
 for w in C2 C3 C4; do
   st=200; [ $w = C4 ] && st=100
