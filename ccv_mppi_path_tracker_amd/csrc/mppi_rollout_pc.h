@@ -123,6 +123,23 @@ __device__ __forceinline__ void pc_rotate_priority(const RolloutArgs& A, const i
     else __builtin_amdgcn_s_setprio(0);
 }
 
+// LDS sequence numbers for hand-offs without a barrier (mppi_rollout_r3.h): written by one wave, polled by another.  The
+// LDS operations of a wave execute in order, so a number written after the data (or after the loads have returned) needs
+// no fence -- and must not get one: a release at workgroup scope would also wait for the wave's global stores.  Relaxed
+// workgroup-scope atomics compile to plain ds_write_b32 / ds_read_b32; the empty asm statements keep the compiler from
+// moving other memory accesses across them.
+__device__ __forceinline__ void pc_publish(int* flag, const int value) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void pc_wait_for(int* flag, const int value) {
+    asm volatile("" ::: "memory");
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < value)
+        __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
 // Workgroup barrier for the block hand-off.  The two waves exchange data through LDS only, so the barrier waits for LDS
 // (lgkmcnt) and not, as __syncthreads() does, for the acknowledgement of every control / state store still in flight.
 __device__ __forceinline__ void pc_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -709,7 +726,8 @@ __device__ __forceinline__ void pc_prune_window(const RolloutArgs& A, const SH& 
 template <int NV, int MODEL, class SH>
 __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, double& cost, const int b, const int lane,
                                            const int i0 = 0,          // states i0 .. i0+NV-1 of block b
-                                           int* prune_on = nullptr) {  // wave-uniform switch of the window pruning (below)
+                                           int* prune_on = nullptr,   // wave-uniform switch of the window pruning (below)
+                                           int* taken_flag = nullptr, const int taken_value = 0) {   // see below
     const int H4 = (A.H + 3) & ~3;   // the window is padded with c = +inf: four points per iteration, no remainder
     double px[NV], py[NV], m[NV];
 #pragma unroll
@@ -721,6 +739,12 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
             py[i] -= A.x0[1];
         }
         m[i] = INFINITY;
+    }
+    if (taken_flag) {
+        // three-wave kernel: the positions of the block are in registers -- tell the producer that the LDS buffer is free
+        // (mppi_rollout_r3.h).  The wait makes sure the loads above have returned before the number is written.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pc_publish(taken_flag, taken_value);
     }
     // software pipeline: the coefficients of points j+4..j+7 are read from LDS (broadcast reads) before the ~100 fp64
     // instructions on points j..j+3 issue, so no iteration waits out the LDS latency.  sh.ab / sh.c carry 4 spare

@@ -10,7 +10,12 @@
 //   wave 1 (distance)   min over the window points of the squared distance for the states of block s-1 (the O(K T^2) part)
 //   wave 2 (store)      controls and states of block s-1: LDS -> HBM; it is the wave that waits on the store path
 //
-// One LDS barrier per time block.  With three waves per workgroup the chip also holds three waves per SIMD at K = 65 536.
+// The hand-off between the waves is a pair of LDS sequence numbers per direction, not a barrier (round 2): the producer
+// publishes "block b is in LDS"; the distance and the store wave publish "block b is in my registers" as soon as they have
+// LOADED it, i.e. before the distance loop and before the (slow) global stores.  The producer only ever waits for the
+// loads of block b-2 before it overwrites that buffer, so neither the distance loop nor a store stall of block b-1 holds up
+// block b+1: with a barrier per block the producer stood at the barrier for 16-18 % of the loop.
+// With three waves per workgroup the chip also holds three waves per SIMD at K = 65 536.
 // The epilogue (weights, fused sum w*u partials) deals the control rows to all three waves.  Arithmetic, noise and the
 // summation order inside a row are those of k_rollout_pc; only the per-sample cost is the sum of the producer's and the
 // distance wave's parts.
@@ -41,7 +46,12 @@ struct R3Shared {
     alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u*
     double us[kStageNoise ? 1 : 2][kStageNoise ? 1 : kTU * udim_of(MODEL)][kPcSamples];   // clamped controls of a block, double buffered
     float zs[kStageNoise ? 2 : 1][kStageNoise ? kTU * udim_of(MODEL) : 1][kPcSamples];    // or their normals
+    // hand-off sequence numbers: [0] blocks the producer has finished writing, [1] / [2] blocks the distance / store wave has
+    // taken into registers
+    int seq[4];
 };
+
+// first part of the hand-off: see pc_publish / pc_wait_for in mppi_rollout_pc.h
 
 // First chunk of the epilogue's re-read for this kernel's row dealing (units of kR3RB rows, wave w owns units w, w+3, ...):
 // with the row of load i a compile-time distance from the wave's first row, an address costs one scalar multiply and
@@ -77,22 +87,11 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
     double cost = 0.0;
     const int nblocks = (H + kTU - 1) / kTU;
     const int nstates = FB ? H - 2 : H;   // states that reach the path cost (dd:199 / fb:409)
+    if (threadIdx.x < 4) sh.seq[threadIdx.x] = 0;
     __syncthreads();
-#if defined(CCV_STAMP)
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long r3_work = 0, r3_t0, r3_t1;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r3_t0)::"memory");
-    const unsigned long long r3_begin = r3_t0;
-#define R3_BARRIER()                                                                          \
-    do {                                                                                       \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r3_t1)::"memory");         \
-        r3_work += r3_t1 - r3_t0;                                                              \
-        pc_barrier_lds();                                                                      \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r3_t0)::"memory");         \
-    } while (0)
-#else
-#define R3_BARRIER() pc_barrier_lds()
-#endif
+    int* const seq_ready = &sh.seq[0];
+    int* const seq_dist = &sh.seq[1];
+    int* const seq_store = &sh.seq[2];
     if (wv == 0) {
         // ---------------- producer: all time blocks, state in registers
         if constexpr (FB && COST) cost += A.w_yaw * (A.x0[2] - A.yaw_ref0) * (A.x0[2] - A.yaw_ref0);   // fb:408
@@ -110,129 +109,121 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
         for (int i = 0; i < 8; ++i) ST.acc[i] = 0;
         ST.last = 0;
 #endif
-        for (int s = 0; s <= nblocks; ++s) {
-            pc_rotate_priority(A, s);
-            if (s < nblocks) {
-                bool done = false;
-                if (s * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, s, lane, k, kk, live, kg
-#if defined(CCV_STAMP)
-                                                                                  , ST
-#endif
-                );
-                if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, s, lane, k, kk, live, kg);
+        for (int b = 0; b < nblocks; ++b) {
+            pc_rotate_priority(A, b);
+            if (b >= 2) {   // the buffers of block b last held block b-2: both readers must have taken it
+                pc_wait_for(seq_dist, b - 1);
+                pc_wait_for(seq_store, b - 1);
             }
-            R3_BARRIER();
+            bool done = false;
+            if (b * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg
+#if defined(CCV_STAMP)
+                                                                              , ST
+#endif
+            );
+            if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
+            pc_publish(seq_ready, b + 1);
         }
     } else if (wv == 1) {
-        // ---------------- distance wave: the first kR3CStates states of block s-1
+        // ---------------- distance wave: the states of block b as soon as the producer has published it
         int prune_on = 1;
-        for (int s = 0; s <= nblocks; ++s) {
-            pc_rotate_priority(A, s);
+        for (int b = 0; b < nblocks; ++b) {
+            pc_rotate_priority(A, b + 1);
+            pc_wait_for(seq_ready, b + 1);
+            bool taken = false;
             if constexpr (COST) {
-                if (s >= 1) {
-                    const int b = s - 1;
-                    const int nv = min(kR3CStates, nstates - b * kTU);
-                    switch (nv) {
-                        case 8: pc_consume<8, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
-                        case 7: pc_consume<7, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
-                        case 6: pc_consume<6, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
-                        case 5: pc_consume<5, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
-                        case 4: pc_consume<4, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
-                        case 3: pc_consume<3, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
-                        case 2: pc_consume<2, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
-                        case 1: pc_consume<1, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
-                        default: break;
-                    }
+                const int nv = min(kR3CStates, nstates - b * kTU);
+                taken = nv > 0;
+                switch (nv) {
+                    case 8: pc_consume<8, MODEL>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 7: pc_consume<7, MODEL>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 6: pc_consume<6, MODEL>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 5: pc_consume<5, MODEL>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 4: pc_consume<4, MODEL>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 3: pc_consume<3, MODEL>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 2: pc_consume<2, MODEL>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 1: pc_consume<1, MODEL>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    default: break;
                 }
             }
-            R3_BARRIER();
+            if (!taken) pc_publish(seq_dist, b + 1);   // (nothing of this block reaches the path cost)
         }
     } else {
-        // ---------------- store wave: controls (sampled here: MODE_FUSED) and states (not in MODE_COST) of block s-1
+        // ---------------- store wave: controls (sampled here: MODE_FUSED) and states (not in MODE_COST) of block b, LDS ->
+        // registers -> HBM.  Everything is read from LDS first and the buffer handed back before the first store issues:
+        // a 512-byte store costs this wave 45-120 cycles, and the producer must not wait for 32 of them.
         constexpr int UD = udim_of(MODEL);
         const size_t pitch = (size_t)A.pitch;
-        for (int s = 0; s <= nblocks; ++s) {
-            pc_rotate_priority(A, s);
-            if (s >= 1) {
-                const int b = s - 1, t0 = b * kTU;
-#if !defined(CCV_ABL_NO_STORE)
-                if constexpr (MODE == MODE_FUSED) {
-                    const int nrows = min(kTU, H - 1 - t0) * UD;   // control steps t < H-1
-                    static_for<kTU * UD>([&](auto RR) {
-                        constexpr int r = decltype(RR)::value;
-                        // rows are padded to a multiple of 64 samples (pitch): lanes past K write their padding slot
-                        if (r < nrows) {
-                            double v;
-                            if constexpr (R3Shared<MODEL>::kStageNoise) {
-                                constexpr int d = r % UD;
-                                v = (double)sh.zs[b & 1][r][lane] * A.sigma + sh.nom[t0 * UD + r];   // as pc_produce*
-                                v = clampd(v, arg5<d>(A.umin), arg5<d>(A.umax));
-                                if constexpr (FB && d == 2) {
-                                    if (A.steer_off) v = 0.0;
-                                }
-                            } else {
-                                v = sh.us[b & 1][r][lane];
-                            }
-                            A.u[(size_t)(t0 * UD + r) * pitch + k] = v;
+        for (int b = 0; b < nblocks; ++b) {
+            pc_rotate_priority(A, b + 1);
+            pc_wait_for(seq_ready, b + 1);
+            const int t0 = b * kTU;
+            double uv[kTU * UD], xv[kTU], yv[kTU];
+            if constexpr (MODE == MODE_FUSED) {
+                static_for<kTU * UD>([&](auto RR) {
+                    constexpr int r = decltype(RR)::value;
+                    if constexpr (R3Shared<MODEL>::kStageNoise) {
+                        constexpr int d = r % UD;
+                        double v = (double)sh.zs[b & 1][r][lane] * A.sigma + sh.nom[t0 * UD + r];   // as pc_produce*
+                        v = clampd(v, arg5<d>(A.umin), arg5<d>(A.umax));
+                        if constexpr (FB && d == 2) {
+                            if (A.steer_off) v = 0.0;
                         }
-                    });
-                }
-                if constexpr (MODE != MODE_COST) {
-                    if (A.store_xy) {
-                        const int nst = min(kTU, H - t0);           // states t < H
+                        uv[r] = v;
+                    } else {
+                        uv[r] = sh.us[b & 1][r][lane];
+                    }
+                });
+            }
+            if constexpr (MODE != MODE_COST) {
 #pragma unroll
-                        for (int tt = 0; tt < kTU; ++tt) {
-                            if (tt < nst) {
-                                CCV_STATE_STORE(&A.xs[(size_t)(t0 + tt) * pitch + k], sh.p[b & 1][tt][0][lane]);
-                                CCV_STATE_STORE(&A.ys[(size_t)(t0 + tt) * pitch + k], sh.p[b & 1][tt][1][lane]);
-                            }
+                for (int tt = 0; tt < kTU; ++tt) {
+                    xv[tt] = sh.p[b & 1][tt][0][lane];
+                    yv[tt] = sh.p[b & 1][tt][1][lane];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pc_publish(seq_store, b + 1);
+#if !defined(CCV_ABL_NO_STORE)
+            if constexpr (MODE == MODE_FUSED) {
+                const int nrows = min(kTU, H - 1 - t0) * UD;   // control steps t < H-1
+                static_for<kTU * UD>([&](auto RR) {
+                    constexpr int r = decltype(RR)::value;
+                    // rows are padded to a multiple of 64 samples (pitch): lanes past K write their padding slot
+                    if (r < nrows) A.u[(size_t)(t0 * UD + r) * pitch + k] = uv[r];
+                });
+            }
+            if constexpr (MODE != MODE_COST) {
+                if (A.store_xy) {
+                    const int nst = min(kTU, H - t0);           // states t < H
+#pragma unroll
+                    for (int tt = 0; tt < kTU; ++tt) {
+                        if (tt < nst) {
+                            CCV_STATE_STORE(&A.xs[(size_t)(t0 + tt) * pitch + k], xv[tt]);
+                            CCV_STATE_STORE(&A.ys[(size_t)(t0 + tt) * pitch + k], yv[tt]);
                         }
                     }
                 }
+            }
 #endif
-            }
-            if constexpr (COST && kR3CStates < kTU) {
-                if (s >= 1) {   // (experiment: the store wave also takes the last states)
-                    const int b = s - 1;
-                    const int nv = min(kTU - kR3CStates, nstates - b * kTU - kR3CStates);
-                    if (nv == 2) pc_consume<2, MODEL>(A, sh, cost, b, lane, kR3CStates);
-                    else if (nv == 1) pc_consume<1, MODEL>(A, sh, cost, b, lane, kR3CStates);
-                }
-            }
-            // the other two waves re-read the control rows in the epilogue: all of this wave's stores are acknowledged
-            // before the last barrier
-            if (s == nblocks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            R3_BARRIER();
         }
+        // the other two waves re-read the control rows in the epilogue: all of this wave's stores are acknowledged before
+        // the barrier below
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
-#if defined(CCV_STAMP)
-    if (A.dbg && lane == 0 && (blockIdx.x == 3 || blockIdx.x == 771)) {
-        // [work cycles, loop cycles] per wave: block 3 (first on its CU) -> slots 0..5, block 771 (last) -> slots 8..13
-        const int o = blockIdx.x == 3 ? 0 : 8;
-        A.dbg[o + wv * 2 + 0] = r3_work;
-        A.dbg[o + wv * 2 + 1] = r3_t0 - r3_begin;
-    }
-    if (A.dbg && lane == 0 && blockIdx.x < 4096 && wv < 2) {
-        // per block: [start, loop end wave 0, hw id wave 0, loop end wave 1, hw id wave 1, kernel end wave 0]
-        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
-        unsigned int hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-        unsigned int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
-        if (wv == 0) A.dbg[64 + blockIdx.x * 6 + 0] = rt0;
-        A.dbg[64 + blockIdx.x * 6 + 1 + 2 * wv] = rt1;
-        A.dbg[64 + blockIdx.x * 6 + 2 + 2 * wv] = ((unsigned long long)xcc << 32) | hwid;
-    }
-#endif
     if constexpr (COST) {
         using Rows = UpdRowsT<kR3RB, kR3Waves>;
         const int R = (H - 1) * udim_of(MODEL);
         double upd[kUpdCH];
         const Rows rows{R, wv};
         const int mcount = A.fuse_update ? rows.count() : 0;
-        // start the re-read of this wave's share of the controls before anything else (see pc_update_fetch)
-        if (mcount > 0) r3_update_fetch0(A, upd, wv, mcount, kk);
         sh.cost[wv][lane] = cost;
+        // the one barrier of the kernel: every wave is through its loop (the store wave with all its stores acknowledged),
+        // the three cost parts are in LDS, and p / ab / c are dead
         pc_barrier_lds();
+        // the re-read of this wave's share of the controls is issued before anything else (see pc_update_fetch)
+        if (mcount > 0) r3_update_fetch0(A, upd, wv, mcount, kk);
         const double total = (sh.cost[0][lane] + sh.cost[1][lane]) + sh.cost[2][lane];
         const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
         if (wv == 0 && live) {
@@ -246,12 +237,6 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
             if (wv == kR3Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
         }
     }
-#if defined(CCV_STAMP)
-    if (A.dbg && lane == 0 && wv == 0 && blockIdx.x < 4096) {
-        __builtin_amdgcn_s_waitcnt(0);
-        A.dbg[64 + blockIdx.x * 6 + 5] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
 }
 
 }  // namespace ccv
