@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02g
-timeout -k 10 600 python -m pytest tests -m gpu -q -x > gpurun_out/r02g/pytest.log 2>&1; rc=$?
-tail -5 gpurun_out/r02g/pytest.log
-[ $rc = 0 ] || exit $rc
 L=$GRAFT_REPO_ROOT/_abl/lib_head.so
-bash tools/ab_bench.sh r02g 3 -- "head=CCV_MPPI_LIB=$L" "flags=X=1"
-BENCH_ARGS="--workload C3 --steps 200 --warmup 20 --no-cpu-baseline" bash tools/ab_bench.sh r02g_c3 2 -- "head=CCV_MPPI_LIB=$L" "flags=X=1"
+bash tools/ab_bench.sh r02i 3 -- "head=CCV_MPPI_LIB=$L" "pts2=X=1"
+BENCH_ARGS="--workload C4 --steps 100 --warmup 10 --no-cpu-baseline" bash tools/ab_bench.sh r02i_c4 3 -- "head=CCV_MPPI_LIB=$L" "pts2=X=1"
+BENCH_ARGS="--samples-per-gpu 524288 --steps 60 --warmup 10 --no-cpu-baseline" bash tools/ab_bench.sh r02i_k512k 3 -- "head=CCV_MPPI_LIB=$L" "pts2=X=1"
+BENCH_ARGS="--workload C3 --steps 200 --warmup 20 --no-cpu-baseline" bash tools/ab_bench.sh r02i_c3 2 -- "head=CCV_MPPI_LIB=$L" "pts2=X=1"
