@@ -34,6 +34,10 @@ struct ccv_mppi_handle {
     // device buffers
     double* d_nominal = nullptr;
     const double* pending_vec = nullptr;   // deferred apply_partials: u* = pending_vec[1..] / pending_vec[0] (see flush_pending)
+    // device-resident loop: the update of a tick is launched together with the next tick's prologue (k_finalize_advance);
+    // anything else that needs u* / the statistics first gets a plain k_finalize (flush_pending)
+    bool fin_pending = false;
+    FinalizeArgs fin_args{};
     double* d_u = nullptr;
     double* d_xs = nullptr;
     double* d_ys = nullptr;
@@ -266,6 +270,11 @@ void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const 
 // A deferred ccv_mppi_apply_partials_enqueue is normally consumed by the next fused rollout launch (pc_stage_nominal);
 // anything else that reads the warm start first gets it materialised here.
 int flush_pending(ccv_mppi_handle* h) {
+    if (h->fin_pending) {
+        hipLaunchKernelGGL(k_finalize, dim3(finalize_blocks(h->fin_args.R)), dim3(kBlock), 0, h->stream, h->fin_args);
+        h->fin_pending = false;
+        HIP_TRY(h, hipGetLastError());
+    }
     if (!h->pending_vec) return CCV_MPPI_OK;
     hipLaunchKernelGGL(k_apply_partials, dim3(1), dim3(kBlock), 0, h->stream, h->pending_vec, h->d_nominal, h->d_stats, h->R);
     h->pending_vec = nullptr;
@@ -311,6 +320,13 @@ int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A_in, const Window& W,
     // the production kernel also reduces its workgroup's share of sum w and sum w*u (no second pass over the controls);
     // the underflow-safe MIN_SHIFT mode needs the global minimum first and keeps the separate update kernels
     A.fuse_update = (h->coop && mode != MODE_ROLLOUT && !(h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT)) ? 1 : 0;
+    if (h->fin_pending) {   // (the kernel reads the warm start)
+        const double* keep = h->pending_vec;
+        h->pending_vec = nullptr;
+        int rc = flush_pending(h);
+        h->pending_vec = keep;
+        if (rc) return rc;
+    }
     if (h->pending_vec) {
         if (h->coop && mode == MODE_FUSED) {   // the kernel divides while it stages u* (and writes it back)
             A.pending_vec = h->pending_vec;
@@ -343,7 +359,10 @@ int launch_sample(ccv_mppi_handle* h, const RolloutArgs& A) {
 }
 
 // weights -> [sum w, sum w*u] (-> u* when `normalise`); vec_out may be a caller-owned device buffer.
-int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out, bool exchange = false) {
+int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out, bool exchange = false, bool defer = false) {
+    if (h->fin_pending) {
+        if (int rc = flush_pending(h)) return rc;
+    }
     int nparts = h->nparts_last;
     if (nparts == 0) {
         // not fused (one-sample-per-lane fallback kernel or MIN_SHIFT): stream w and the controls once more
@@ -389,6 +408,11 @@ int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out, bool exch
         hipLaunchKernelGGL(k_finalize_exchange, dim3(finalize_blocks(h->R)), dim3(kBlock), 0, h->stream, F, X);
         HIP_TRY(h, hipGetLastError());
         h->pending_vec = h->d_xvec;   // u* = reduced[1..] / reduced[0]: deferred like ccv_mppi_apply_partials_enqueue
+        return CCV_MPPI_OK;
+    }
+    if (defer && nparts == h->nblocks && normalise) {   // fused partials, plain update: launched with the next tick's prologue
+        h->fin_args = F;
+        h->fin_pending = true;
         return CCV_MPPI_OK;
     }
     hipLaunchKernelGGL(k_finalize, dim3(finalize_blocks(h->R)), dim3(kBlock), 0, h->stream, F);
@@ -466,7 +490,7 @@ int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const dou
     int rc = launch_rollout(h, A, W, MODE_FUSED);
     h->ev_kernel_start = h->ev_kernel_stop = nullptr;
     if (rc) return rc;
-    rc = launch_update(h, normalise, vec_out, exchange);
+    rc = launch_update(h, normalise, vec_out, exchange, /*defer=*/resident && normalise && !vec_out && !exchange && !timed);
     if (rc) return rc;
     if (timed) HIP_TRY(h, hipEventRecord(h->ev[slot + 2], h->stream));
     if (h->throttle && ++h->enqueued % ccv_mppi_handle::kThrottleEvery == 0) {
@@ -738,6 +762,7 @@ int ccv_mppi_synchronize(ccv_mppi_handle* h) {
 int ccv_mppi_set_nominal(ccv_mppi_handle* h, const double* u) {
     if (!h || !u) return CCV_MPPI_ERR_INVALID_ARG;
     h->pending_vec = nullptr;   // overwritten anyway
+    if (int rc = flush_pending(h)) return rc;   // (a deferred update of the resident loop must not land on top of it)
     HIP_TRY(h, hipMemcpyAsync(h->d_nominal, u, (size_t)h->R * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     // (the resident loop's plant integrates u*[0]: its angle bounds must cover what the caller put there; NaN sticks)
@@ -1023,7 +1048,8 @@ int resident_step(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, i
         if (!h->coop || !fast_trig_safe(h, chk, MODE_FUSED) || !(heading_bound <= kFastTrigLimit))
             return fail(h, CCV_MPPI_ERR_STATE, "the resident loop needs the cooperative kernels and bounded pose angles / commands");
     }
-    if (advance) {
+    const bool fuse = h->fin_pending && !h->pending_vec;   // the last tick's update is still to be launched: together with this prologue
+    if (advance && !fuse) {
         if (int rc = flush_pending(h)) return rc;   // the command is u*[0]: a deferred division has to happen now
     }
     AdvanceArgs V;
@@ -1040,7 +1066,13 @@ int resident_step(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, i
     V.model = h->cfg.model;
     V.advance = advance ? 1 : 0;
     V.trace_cap = ccv_mppi_handle::kTraceRows;
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(kAdvanceThreads), 0, h->stream, V);
+    if (fuse) {
+        hipLaunchKernelGGL(k_finalize_advance, dim3(finalize_blocks(h->fin_args.R) + 1), dim3(kBlock), 0, h->stream, h->fin_args, V);
+        h->fin_pending = false;
+    } else {
+        if (int rc = flush_pending(h)) return rc;
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(kAdvanceThreads), 0, h->stream, V);
+    }
     HIP_TRY(h, hipGetLastError());
     h->res_steps += 1;
     for (int i = 0; i < 3; ++i) h->res_angle_abs[i] = nb[i];
@@ -1269,6 +1301,7 @@ int ccv_mppi_read_weights(ccv_mppi_handle* h, int32_t first, int32_t count, doub
     if (rc) return rc;
     if (!h->have_weights) return fail(h, CCV_MPPI_ERR_STATE, "no weights yet");
     if (count == 0) return CCV_MPPI_OK;
+    if ((rc = flush_pending(h)) != CCV_MPPI_OK) return rc;   // (sum w)
     rc = ensure_scratch(h, (size_t)count * sizeof(double));
     if (rc) return rc;
     hipLaunchKernelGGL(k_normalise_weights, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_w, h->d_stats,

@@ -580,7 +580,7 @@ __device__ __forceinline__ void finalize_cost_stats(const FinalizeArgs& A, const
 }
 constexpr int finalize_blocks(int R) { return (R + 2 + kBlock / 64 - 1) / (kBlock / 64); }   // waves: R rows, sum w, statistics
 
-__global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
+__device__ __forceinline__ void finalize_rows(const FinalizeArgs& A) {
     const int lane = threadIdx.x & 63;
     // rows 0..R-1: one wave each; wave R: sum w; wave R + 1: the cost statistics
     const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -603,6 +603,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) {
         A.stats[0] = s;
     }
 }
+__global__ __launch_bounds__(kBlock) void k_finalize(const FinalizeArgs A) { finalize_rows(A); }
 
 // ---- K sharded over the GPUs of one node without a collective library call ---------------------------
 // The exchanged message is 1 + (H-1)*u_dim doubles (<= 3.2 KB): far below the size at which a ring all-reduce pays, and a

@@ -31,41 +31,43 @@ struct AdvanceArgs {
 
 constexpr int kAdvanceThreads = 1024;   // one workgroup; a path of a few thousand poses is one or two batches of loads per thread
 
-__global__ __launch_bounds__(kAdvanceThreads) void k_advance(const AdvanceArgs A) {
-    __shared__ double s_d[kAdvanceThreads / 64];
-    __shared__ int s_i[kAdvanceThreads / 64];
+// NT threads of one workgroup; cmd: the command u*[0][0 .. u_dim) (read only when A.advance)
+template <int NT>
+__device__ __forceinline__ void advance_body(const AdvanceArgs& A, const double* cmd) {
+    __shared__ double s_d[NT / 64];
+    __shared__ int s_i[NT / 64];
     __shared__ int s_start;
     ResidentFrame& F = *A.frame;
     // ---- pose (every thread computes it: wave-uniform, no hand-off)
     double x = F.x0[0], y = F.x0[1], yaw = F.x0[2], roll = F.x0[3], pitch = F.x0[4];
     if (A.advance) {
-        const double v = A.nominal[0], w = A.nominal[1];
-        const double heading = A.model == CCV_MPPI_DIFF_DRIVE ? yaw : yaw + A.nominal[2];
+        const double v = cmd[0], w = cmd[1];
+        const double heading = A.model == CCV_MPPI_DIFF_DRIVE ? yaw : yaw + cmd[2];
         double sn, cs;
         fast_sincos(heading, sn, cs);
         x = x + v * cs * A.dt;
         y = y + v * sn * A.dt;
         yaw = rebase_angle(yaw + w * A.dt);
         if (A.model == CCV_MPPI_FULL_BODY) {
-            roll = rebase_angle(roll + A.nominal[3] * A.dt);
-            pitch = rebase_angle(pitch + A.nominal[4] * A.dt);
+            roll = rebase_angle(roll + cmd[3] * A.dt);
+            pitch = rebase_angle(pitch + cmd[4] * A.dt);
         }
     }
     // ---- get_CurrentIndex(): strict '<' against a running minimum that starts at the 100 m gate
     double best_d = 100.0;
     int best_i = -1;
     constexpr int kBatch = 4;   // loads in flight per thread: the scan is a chain of memory latencies otherwise
-    for (int i0 = threadIdx.x; i0 < A.n_path; i0 += kAdvanceThreads * kBatch) {
+    for (int i0 = threadIdx.x; i0 < A.n_path; i0 += NT * kBatch) {
         double qx[kBatch], qy[kBatch];
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
-            const int i = min(i0 + b * kAdvanceThreads, A.n_path - 1);
+            const int i = min(i0 + b * NT, A.n_path - 1);
             qx[b] = A.path_x[i];
             qy[b] = A.path_y[i];
         }
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
-            const int i = i0 + b * kAdvanceThreads;
+            const int i = i0 + b * NT;
             const double ex = x - qx[b], ey = y - qy[b];
             const double d = sqrt(ex * ex + ey * ey);
             if (i < A.n_path && d < best_d) {   // (ascending i within a thread: the first of equal distances stays)
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(kAdvanceThreads) void k_advance(const AdvanceArgs A
     }
     __syncthreads();   // (also: every thread has read the old pose)
     if (wave == 0) {
-        constexpr int NW = kAdvanceThreads / 64;
+        constexpr int NW = NT / 64;
         const double d2 = lane < NW ? s_d[lane] : 100.0;
         const int i2 = lane < NW ? s_i[lane] : -1;
         double fd;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(kAdvanceThreads) void k_advance(const AdvanceArgs A
     const int start = s_start;
     // ---- calc_RefPath(): the index is the truncation of a double; past the end the final pose repeats
     const double stride = A.v_ref * A.dt / A.resolution;
-    for (int i = threadIdx.x; i < A.H; i += kAdvanceThreads) {
+    for (int i = threadIdx.x; i < A.H; i += NT) {
         const int idx = (int)(start + i * stride);   // (the host admits 0 < dt < inf only: idx >= 0)
         const int src = idx < A.n_path ? idx : A.n_path - 1;
         const double xr = A.path_x[src], yr = A.path_y[src];
@@ -137,6 +139,32 @@ __global__ __launch_bounds__(kAdvanceThreads) void k_advance(const AdvanceArgs A
             t[5] = (double)start;
         }
     }
+}
+
+__global__ __launch_bounds__(kAdvanceThreads) void k_advance(const AdvanceArgs A) { advance_body<kAdvanceThreads>(A, A.nominal); }
+
+// The update of tick i and the prologue of tick i+1 in ONE launch (the closed loop then costs two launches per tick, not
+// three): blocks 0 .. finalize_blocks(R)-1 are k_finalize; one more block forms the command u*[0][d] = V_d / S from the same
+// partial sums in the same order (the same bits the finalize waves write into the warm start -- it cannot wait for them)
+// and runs the prologue with it.
+__global__ __launch_bounds__(kBlock) void k_finalize_advance(const FinalizeArgs F, const AdvanceArgs A) {
+    if ((int)blockIdx.x < finalize_blocks(F.R)) {
+        finalize_rows(F);
+        return;
+    }
+    __shared__ double cmd[CCV_MPPI_MAX_UDIM + 3];
+    if (A.advance) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ud = udim_of(A.model);
+        for (int d = wv; d < ud; d += kBlock / 64) {
+            double s, v;
+            lane_partial_sum2(F.partial + (size_t)F.R * F.nchunks, F.partial + (size_t)d * F.nchunks, F.nchunks, lane, s, v);
+            s = wave_sum(s);
+            v = wave_sum(v);
+            if (lane == 0) cmd[d] = v / s;
+        }
+    }
+    __syncthreads();
+    advance_body<kBlock>(A, cmd);
 }
 
 }  // namespace ccv

@@ -186,7 +186,8 @@ int ccv_mppi_iterate_exchange_enqueue(ccv_mppi_handle* h, const double* x0, doub
  *                  predict_NextState(), dd:104-109 / sd:120-125 / fb:445-452: the closed-loop plant, what the robot does
  *                  between two ticks; ccv_mppi_plant_step() in ccv_mppi_host.h is the same arithmetic on the host)
  *   get_CurrentIndex() (dd:126-140) + calc_RefPath() (dd:156-181) from that pose, then the iteration itself
- * with no host data in between: a closed loop costs three kernel launches per tick and no PCIe traffic.  Window, index
+ * with no host data in between: a closed loop costs two kernel launches per tick (the update of a tick is launched together
+ * with the prologue of the next one) and no PCIe traffic.  Window, index
  * and pose are bit-identical to ccv_mppi_calc_ref_path() / ccv_mppi_plant_step() on the host; yaw_ref[0] (read by fb:408
  * only) comes from the device atan2 and may differ from libm's in the last place.  v_ref and the horizon are the
  * handle's; `resolution` is the spacing of the path poses (resolution_, dd:160).  Needs the default (cooperative)
