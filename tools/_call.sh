@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02k
-timeout -k 10 500 python tests/soak_determinism.py 20000 2>&1 | tee gpurun_out/r02k/soak_determinism.txt
+bash tools/ab_bench.sh r02m2 2 -- "reread=CCV_MPPI_KEEP=0" "keep=X=1" "keeploop_reread_epi=CCV_MPPI_LIB=$GRAFT_REPO_ROOT/_abl/lib_keeploop.so"
