@@ -39,6 +39,9 @@ struct ccv_mppi_handle {
     bool fin_pending = false;
     FinalizeArgs fin_args{};
     double* d_u = nullptr;
+    float* d_z = nullptr;              // the fused iteration stores the normals in place of the controls (mppi_kernels.h)
+    double* d_nom_used = nullptr;      // ... and the warm start they were drawn around
+    bool controls_in_z = false;        // d_u is stale: the controls of the last iteration are (d_z, d_nom_used)
     double* d_xs = nullptr;
     double* d_ys = nullptr;
     double* d_cost = nullptr;
@@ -185,6 +188,8 @@ void fill_args(const ccv_mppi_handle* h, RolloutArgs& A, const double* x0, doubl
     A.steer_off = (c.flags & CCV_MPPI_FLAG_STEER_OFF) ? 1 : 0;
     A.nominal = h->d_nominal;
     A.u = h->d_u;
+    A.z = h->d_z;
+    A.nominal_used = h->d_nom_used;
     A.xs = h->d_xs;
     A.ys = h->d_ys;
     A.cost = h->d_cost;
@@ -282,6 +287,30 @@ int flush_pending(ccv_mppi_handle* h) {
     return CCV_MPPI_OK;
 }
 
+// The fused kernels store the normals, not the controls; whoever needs the controls as an array (the stage-wise calls after a
+// fused iteration, the unfused update) gets them re-derived into d_u first: the samplers' arithmetic, the same bits.
+int materialize_controls(ccv_mppi_handle* h) {
+    if (!h->controls_in_z) return CCV_MPPI_OK;
+    MaterializeArgs M;
+    M.z = h->d_z;
+    M.nominal_used = h->d_nom_used;
+    M.u = h->d_u;
+    M.sigma = h->cfg.control_noise;
+    for (int d = 0; d < CCV_MPPI_MAX_UDIM; ++d) {
+        M.umin[d] = h->cfg.u_min[d];
+        M.umax[d] = h->cfg.u_max[d];
+    }
+    M.K = h->K;
+    M.pitch = h->pitch;
+    M.R = h->R;
+    M.udim = h->udim;
+    M.zero_dim = (h->cfg.model == CCV_MPPI_FULL_BODY && (h->cfg.flags & CCV_MPPI_FLAG_STEER_OFF)) ? 2 : -1;
+    hipLaunchKernelGGL(k_materialize_controls, dim3((h->K + kBlock - 1) / kBlock, h->R), dim3(kBlock), 0, h->stream, M);
+    HIP_TRY(h, hipGetLastError());
+    h->controls_in_z = false;
+    return CCV_MPPI_OK;
+}
+
 // k_rollout_pc uses a branch-free sin/cos that is valid for |angle| <= kFastTrigLimit.  Every heading a sample can
 // reach is bounded by the start angle plus (H-1) steps at the largest control magnitude, so the decision is made here,
 // once per call; anything else (huge or non-finite angles, unbounded injected controls) runs the plain
@@ -337,12 +366,16 @@ int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A_in, const Window& W,
         }
     }
     if (mode != MODE_ROLLOUT) h->nparts_last = A.fuse_update ? h->nblocks : 0;
+    if (mode != MODE_FUSED) {   // the stage-wise kernels read the controls as an array
+        if (int rc = materialize_controls(h)) return rc;
+    }
     switch (h->cfg.model) {
         case CCV_MPPI_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_DIFF_DRIVE>(h, A, W, mode); break;
         case CCV_MPPI_STEERING_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_STEERING_DIFF_DRIVE>(h, A, W, mode); break;
         default: launch_rollout_model<CCV_MPPI_FULL_BODY>(h, A, W, mode); break;
     }
     HIP_TRY(h, hipGetLastError());
+    if (mode == MODE_FUSED) h->controls_in_z = h->coop != 0;   // (the plain kernel writes u itself)
     return CCV_MPPI_OK;
 }
 
@@ -366,6 +399,7 @@ int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out, bool exch
     int nparts = h->nparts_last;
     if (nparts == 0) {
         // not fused (one-sample-per-lane fallback kernel or MIN_SHIFT): stream w and the controls once more
+        if (int rc = materialize_controls(h)) return rc;
         if (h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT) {
             hipLaunchKernelGGL(k_min_cost, dim3(1), dim3(1024), 0, h->stream, h->d_cost, h->K, h->d_cmin);
             hipLaunchKernelGGL(k_reweight, dim3((h->K + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_cost, h->d_cmin,
@@ -667,6 +701,7 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     const size_t P = (size_t)h->pitch;
     struct { double** p; size_t n; } allocs[] = {
         {&h->d_nominal, (size_t)(CCV_MPPI_MAX_HORIZON + 8) * CCV_MPPI_MAX_UDIM},   // padded: read 4 at a time
+        {&h->d_nom_used, (size_t)(CCV_MPPI_MAX_HORIZON + 8) * CCV_MPPI_MAX_UDIM},
         {&h->d_u, (size_t)h->R * P},
         {&h->d_xs, (size_t)h->H * P},
         {&h->d_ys, (size_t)h->H * P},
@@ -682,6 +717,8 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
         if ((e = hipMalloc(a.p, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
         if ((e = hipMemset(*a.p, 0, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipMemset", e);
     }
+    if ((e = hipMalloc(&h->d_z, (size_t)h->R * P * sizeof(float))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
+    if ((e = hipMemset(h->d_z, 0, (size_t)h->R * P * sizeof(float))) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipMemset", e);
 #if defined(CCV_STAMP)
     if ((e = hipMalloc(&h->d_dbg, (64 + 6 * 4096) * sizeof(unsigned long long))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
 #endif
@@ -709,7 +746,7 @@ int ccv_mppi_destroy(ccv_mppi_handle* h) {
         if (e) (void)hipEventDestroy(e);
     exchange_release(h);
     void* bufs[] = {h->d_nominal, h->d_u, h->d_xs, h->d_ys, h->d_cost, h->d_w, h->d_partial, h->d_statpart, h->d_vec, h->d_stats,
-                    h->d_cmin, h->d_scratch, h->d_frame, h->d_path, h->d_trace, h->d_dbg};
+                    h->d_cmin, h->d_scratch, h->d_frame, h->d_path, h->d_trace, h->d_dbg, h->d_z, h->d_nom_used};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -1147,6 +1184,7 @@ int ccv_mppi_sample(ccv_mppi_handle* h, uint64_t seed, uint64_t iter) {
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (int d = 0; d < h->udim; ++d) h->inj_absmax[d] = std::fmax(std::fabs(h->cfg.u_min[d]), std::fabs(h->cfg.u_max[d]));
+    h->controls_in_z = false;
     h->have_controls = true;
     h->have_rollout = h->have_weights = false;
     return CCV_MPPI_OK;
@@ -1166,6 +1204,7 @@ int ccv_mppi_inject_controls(ccv_mppi_handle* h, const double* u_samples) {
         }
     HIP_TRY(h, hipMemcpyAsync(h->d_u, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->controls_in_z = false;
     h->have_controls = true;
     h->have_rollout = h->have_weights = false;
     return CCV_MPPI_OK;
@@ -1319,6 +1358,27 @@ int ccv_mppi_read_controls(ccv_mppi_handle* h, int32_t first, int32_t count, dou
     if (count == 0) return CCV_MPPI_OK;
     std::vector<double> tmp((size_t)h->R * count);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->controls_in_z) {
+        // the fused iteration kept the normals and the warm start they were drawn around: u = clamp(double(z) * sigma + u*[n]),
+        // the samplers' operations (this file is compiled with -ffp-contract=off: a multiply and an add, as on the device)
+        std::vector<float> zt((size_t)h->R * count);
+        std::vector<double> nom((size_t)h->R);
+        HIP_TRY(h, hipMemcpy2D(zt.data(), (size_t)count * sizeof(float), h->d_z + first, (size_t)h->pitch * sizeof(float),
+                               (size_t)count * sizeof(float), (size_t)h->R, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(nom.data(), h->d_nom_used, (size_t)h->R * sizeof(double), hipMemcpyDeviceToHost));
+        const bool steer_off = h->cfg.model == CCV_MPPI_FULL_BODY && (h->cfg.flags & CCV_MPPI_FLAG_STEER_OFF);
+        for (int n = 0; n < h->R; ++n) {
+            const int d = n % h->udim;
+            const double lo = h->cfg.u_min[d], hi = h->cfg.u_max[d], sigma = h->cfg.control_noise;
+            for (int i = 0; i < count; ++i) {
+                const double prod = (double)zt[(size_t)n * count + i] * sigma;
+                double v = prod + nom[n];
+                v = v < lo ? lo : (v > hi ? hi : v);
+                if (steer_off && d == 2) v = 0.0;
+                tmp[(size_t)n * count + i] = v;
+            }
+        }
+    } else
     HIP_TRY(h, hipMemcpy2D(tmp.data(), (size_t)count * sizeof(double), h->d_u + first, (size_t)h->pitch * sizeof(double),
                            (size_t)count * sizeof(double), (size_t)h->R, hipMemcpyDeviceToHost));
     for (int i = 0; i < count; ++i)

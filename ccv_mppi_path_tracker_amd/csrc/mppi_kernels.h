@@ -8,7 +8,12 @@
 //   k_gather_xy      strided read-back feeding publish_CandidatePath() (dd:265-294)
 //
 // Data layout in HBM (all fp64, k fastest => every store/load of a wave is one contiguous 512-byte run):
-//   u    [(H-1)*u_dim][pitch]   row n = t*u_dim + d  clamped sample controls (sample[i].v_[t] ... in the reference)
+//   u    [(H-1)*u_dim][pitch]   row n = t*u_dim + d  clamped sample controls (sample[i].v_[t] ... in the reference); written by
+//                               the stage-wise calls and the plain kernel only -- the fused iteration stores, in its place,
+//   z    [(H-1)*u_dim][pitch]   fp32: the N(0,1) variate each control was made from, with the warm start it was made around
+//                               (nominal_used): u = clamp(double(z) * sigma + u*[n]) is re-derived, bit for bit, where it is
+//                               needed (epilogue, ccv_mppi_read_controls, k_materialize_controls) -- half the bytes to store and
+//                               to re-read
 //   xs,ys[H][pitch]             sample[i].x_[t], sample[i].y_[t]
 //   cost [pitch], w [pitch]     per-sample cost and unnormalised weight exp(-cost/lambda)
 //   nominal [(H-1)*u_dim]       optimal_solution controls (resident warm start)
@@ -69,6 +74,8 @@ struct RolloutArgs {
     int32_t steer_off, store_u, store_xy, do_cost;
     const double* __restrict__ nominal;
     double* u;
+    float* z;                 // fused iteration: the normals, in place of u (see the layout comment at the top)
+    double* nominal_used;     // ... and the warm start they were made around (written by workgroup 0)
     double* xs;
     double* ys;
     double* cost;
@@ -371,6 +378,27 @@ __global__ __launch_bounds__(kBlock) void k_sample(const RolloutArgs A) {
             A.u[(size_t)n * A.pitch + k] = v;
         }
     }
+}
+
+// u = clamp(double(z) * sigma + u*[n]) for every sample and row, from the normals the fused iteration stored: for the
+// stage-wise calls after a fused iteration and for the unfused update (MIN_SHIFT).  Same operations as the samplers.
+struct MaterializeArgs {
+    const float* z;
+    const double* nominal_used;
+    double* u;
+    double sigma;
+    double umin[5], umax[5];
+    int32_t K, pitch, R, udim, zero_dim;   // zero_dim: the control dimension that steer_off forces to 0 (fb:517), or -1
+};
+__global__ __launch_bounds__(kBlock) void k_materialize_controls(const MaterializeArgs A) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    const int n = blockIdx.y;
+    if (k >= A.K) return;
+    const int d = n % A.udim;
+    double v = (double)A.z[(size_t)n * A.pitch + k] * A.sigma + A.nominal_used[n];
+    v = clampd(v, A.umin[d], A.umax[d]);
+    if (d == A.zero_dim) v = 0.0;
+    A.u[(size_t)n * A.pitch + k] = v;
 }
 
 // ---- weighted update -------------------------------------------------------------------------------------------

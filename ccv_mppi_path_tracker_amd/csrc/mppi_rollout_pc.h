@@ -94,12 +94,32 @@ __device__ __forceinline__ void pc_stage_nominal(const RolloutArgs& A, SH& sh, c
         for (int j = threadIdx.x; j < R + 8; j += nthreads) {
             const double v = j < R ? A.pending_vec[1 + j] / S : 0.0;
             sh.nom[j] = v;
-            if (blockIdx.x == 0 && j < R) A.nominal_w[j] = v;
+            if (blockIdx.x == 0 && j < R) {
+                A.nominal_w[j] = v;
+                A.nominal_used[j] = v;
+            }
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) A.stats_w[0] = S;
         return;
     }
-    for (int j = threadIdx.x; j < R + 8; j += nthreads) sh.nom[j] = j < R ? A.nominal[j] : 0.0;
+    for (int j = threadIdx.x; j < R + 8; j += nthreads) {
+        const double v = j < R ? A.nominal[j] : 0.0;
+        sh.nom[j] = v;
+        if (blockIdx.x == 0 && j < R) A.nominal_used[j] = v;   // (the normals are stored, not the controls: kept with them)
+    }
+}
+
+// The control of row n = t * u_dim + d from its normal: the samplers' arithmetic (double(z) * sigma + mean, clamp, steer_off),
+// so the same bits as the value the rollout used.  D = n % u_dim is a template argument: the clamp bounds then are scalar
+// kernel arguments (a run-time dimension would cost an integer division and two LDS reads with their waits per value).
+template <int MODEL, int D, class SH>
+__device__ __forceinline__ double pc_control_from_normal(const RolloutArgs& A, const SH& sh, const float z, const int n) {
+    double v = (double)z * A.sigma + sh.nom[n];
+    v = clampd(v, arg5<D>(A.umin), arg5<D>(A.umax));
+    if constexpr (MODEL == CCV_MPPI_FULL_BODY && D == 2) {
+        if (A.steer_off) v = 0.0;   // fb:517
+    }
+    return v;
 }
 
 // The candidate states x, y are written once and not read again by this kernel: streaming (non-temporal) stores keep
@@ -212,7 +232,7 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
                             else sh.us[b & 1][nloc][lane] = v;
                         } else {
 #if !defined(CCV_ABL_NO_STORE)
-                            if (live) A.u[(size_t)n * pitch + k] = v;
+                            if (live) A.z[(size_t)n * pitch + k] = zq[q];
 #endif
                         }
                     } else {
@@ -386,7 +406,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
 #if !defined(CCV_ABL_NO_STORE)
                     // no `live` predicate: rows are padded to a multiple of 64 samples (pitch), lanes past K write their
                     // padding slot -- a branch per store would cut this block into pieces the scheduler cannot interleave
-                    A.u[(size_t)(t0 * UD + nloc) * pitch + k] = v;
+                    A.z[(size_t)(t0 * UD + nloc) * pitch + k] = z[i];
 #endif
                 }
             });
@@ -833,20 +853,27 @@ using UpdRows = UpdRowsT<kTU * udim_of(MODEL), kPcWaves>;
 
 // The re-read of this workgroup's controls: the loads of a whole chunk of rows are issued back to back, so the chunk
 // pays one memory latency, not one per batch.  Rows past the end are clamped (loaded, never used).
-template <class ROWS>
-__device__ __forceinline__ void pc_update_fetch(const RolloutArgs& A, double (&v)[kUpdCH], const ROWS& rows, const int m0,
+// T = float: the fused iteration stored the normals (A.z); T = double: the stage-wise calls hold the controls themselves (A.u)
+template <int MODE>
+using UpdT = std::conditional_t<MODE == MODE_FUSED, float, double>;
+template <class T, class ROWS>
+__device__ __forceinline__ void pc_update_fetch(const RolloutArgs& A, T (&v)[kUpdCH], const ROWS& rows, const int m0,
                                                 const int mcount, const int kk) {
     const size_t pitch = (size_t)A.pitch;
 #pragma unroll
-    for (int i = 0; i < kUpdCH; ++i) v[i] = A.u[(size_t)rows.row(min(m0 + i, mcount - 1)) * pitch + kk];
+    for (int i = 0; i < kUpdCH; ++i) {
+        const size_t at = (size_t)rows.row(min(m0 + i, mcount - 1)) * pitch + kk;
+        if constexpr (std::is_same<T, float>::value) v[i] = A.z[at];
+        else v[i] = A.u[at];
+    }
 }
 
 // sum_k w_k * u_k[row] over the 64 samples of the workgroup for this wave's rows -> A.partial[row][workgroup].
 // RB rows at a time through the wave-private LDS buffer `buf` (RB * 65 doubles): every lane drops w*u for each row, then
 // lane (r, q) adds 16 of the 64 entries of row r and two shuffles finish the row.  (The caller has fetched the first
 // chunk into v.)
-template <int RB, class ROWS>
-__device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, double* buf, double (&v)[kUpdCH], const ROWS& rows,
+template <int RB, int MODEL, class SH, class T, class ROWS>
+__device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, const SH& sh, double* buf, T (&v)[kUpdCH], const ROWS& rows,
                                                const int mcount, const double wgt, const int lane, const int kk) {
     static_assert(RB <= 16 && kUpdCH % RB == 0, "batch size");
     constexpr int STRIDE = kPcSamples + 1;   // padded row: lanes (r, q) hit different banks
@@ -858,8 +885,20 @@ __device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, double* buf
             const int base = chunk0 + bb * RB;
             const int nrows = min(RB, mcount - base);
             if (nrows > 0) {
-#pragma unroll
-                for (int r = 0; r < RB; ++r) buf[r * STRIDE + lane] = wgt * v[bb * RB + r];
+                static_for<RB>([&](auto RR) {
+                    constexpr int r = decltype(RR)::value;
+                    if constexpr (std::is_same<T, float>::value) {
+                        // the row's control dimension: rows are dealt in units of ROWS::BR (a multiple of u_dim) and chunks of
+                        // kUpdCH (= 60: a multiple of 2, 3 and 5), so it only depends on the position inside the chunk
+                        constexpr int UD = udim_of(MODEL);
+                        static_assert(ROWS::BR % UD == 0 && kUpdCH % UD == 0, "row dealing vs control dimension");
+                        constexpr int d = (bb * RB + r) % UD;
+                        const int row = rows.row(min(base + r, mcount - 1));   // (rows past the end: clamped, never summed)
+                        buf[r * STRIDE + lane] = wgt * pc_control_from_normal<MODEL, d>(A, sh, v[bb * RB + r], row);
+                    } else {
+                        buf[r * STRIDE + lane] = wgt * v[bb * RB + r];
+                    }
+                });
                 __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed (wave-private buffer)
                 __builtin_amdgcn_wave_barrier();
                 double acc = 0.0;
@@ -891,13 +930,13 @@ __device__ __forceinline__ void pc_block_stats(const RolloutArgs& A, const int R
     }
 }
 
-template <int MODEL>
-__device__ __forceinline__ void pc_partial_update(const RolloutArgs& A, PcShared<MODEL>& sh, double (&v)[kUpdCH],
+template <int MODEL, class T>
+__device__ __forceinline__ void pc_partial_update(const RolloutArgs& A, PcShared<MODEL>& sh, T (&v)[kUpdCH],
                                                   const UpdRows<MODEL>& rows, const int mcount, const double wgt,
                                                   const double total, const int lane, const int wv, const int kk,
                                                   const bool live) {
     // sh.p: 8 * 2 * 64 = 1024 doubles per wave, free after the last consume (the caller has passed the barrier)
-    pc_reduce_rows<kUpdRB>(A, &sh.p[wv][0][0][0], v, rows, mcount, wgt, lane, kk);
+    pc_reduce_rows<kUpdRB, MODEL>(A, sh, &sh.p[wv][0][0][0], v, rows, mcount, wgt, lane, kk);
     if (wv == 0) pc_block_stats(A, (A.H - 1) * udim_of(MODEL), wgt, total, live, lane);
 }
 
@@ -1049,7 +1088,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
     }
 #endif
     if constexpr (COST) {
-        double upd[kUpdCH];
+        UpdT<MODE> upd[kUpdCH];
         const UpdRows<MODEL> rows{(H - 1) * udim_of(MODEL), wv};
         const int mcount = A.fuse_update ? rows.count() : 0;
         // start the re-read of this wave's controls before anything else (see pc_update_fetch)

@@ -30,13 +30,12 @@ constexpr int kR3Waves = 3;
 constexpr int kR3CStates = 8;
 constexpr int kR3RB = 12;   // rows per LDS transpose batch in the epilogue: 3 waves x 12 x 65 doubles fit p + ab + c
 
-// u_dim = 2: the fp64 controls of a block are staged (2 x 8 KB).  u_dim = 3: four workgroups per CU only fit if the
-// fp32 normals are staged instead (2 x 6 KB) -- the store wave then forms u = clamp(z * sigma + u*) a second time, with
-// the producer's arithmetic (it has the issue slots to spare).
+// What the producer stages for the store wave besides the positions: the fp32 normals of the block (2 x 4 KB at u_dim = 2,
+// 2 x 6 KB at u_dim = 3) -- they are what is stored (mppi_kernels.h, layout comment: z in place of u).
 template <int MODEL>
 struct R3Shared {
     static constexpr bool kStage = true;
-    static constexpr bool kStageNoise = udim_of(MODEL) > 2;
+    static constexpr bool kStageNoise = true;
     static constexpr int kPBuf = 2;
     // (p, ab, c are contiguous and are reused as the epilogue's transpose buffers)
     double p[2][kTU][2][kPcSamples];                       // absolute (x,y) of the 8 states of a block, double buffered
@@ -44,8 +43,8 @@ struct R3Shared {
     double c[kMaxH + 4];
     double cost[kR3Waves][kPcSamples];
     alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u*
-    double us[kStageNoise ? 1 : 2][kStageNoise ? 1 : kTU * udim_of(MODEL)][kPcSamples];   // clamped controls of a block, double buffered
-    float zs[kStageNoise ? 2 : 1][kStageNoise ? kTU * udim_of(MODEL) : 1][kPcSamples];    // or their normals
+    double us[1][1][kPcSamples];                           // (unused: the building blocks name it)
+    float zs[2][kTU * udim_of(MODEL)][kPcSamples];         // normals of a block, double buffered
     // hand-off sequence numbers: [0] blocks the producer has finished writing, [1] / [2] blocks the distance / store wave has
     // taken into registers
     int seq[4];
@@ -56,14 +55,17 @@ struct R3Shared {
 // First chunk of the epilogue's re-read for this kernel's row dealing (units of kR3RB rows, wave w owns units w, w+3, ...):
 // with the row of load i a compile-time distance from the wave's first row, an address costs one scalar multiply and
 // one vector add instead of the ~12 scalar instructions of the generic clamped form (60 loads per wave: ~1.3 us).
-__device__ __forceinline__ void r3_update_fetch0(const RolloutArgs& A, double (&v)[kUpdCH], const int wv, const int mcount,
+template <class T>
+__device__ __forceinline__ void r3_update_fetch0(const RolloutArgs& A, T (&v)[kUpdCH], const int wv, const int mcount,
                                                  const int kk) {
     const size_t pitch = (size_t)A.pitch;
-    const double* p0 = A.u + kk + (size_t)(wv * kR3RB) * pitch;
+    const T* p0;
+    if constexpr (std::is_same<T, float>::value) p0 = A.z + kk + (size_t)(wv * kR3RB) * pitch;   // fused: the normals
+    else p0 = A.u + kk + (size_t)(wv * kR3RB) * pitch;
 #pragma unroll
     for (int i = 0; i < kUpdCH; ++i) {
         const size_t rows_ahead = (size_t)((i / kR3RB) * (kR3Waves * kR3RB) + i % kR3RB);   // constant after unrolling
-        v[i] = 0.0;
+        v[i] = 0;
         if (i < mcount) v[i] = p0[rows_ahead * pitch];
     }
 }
@@ -158,22 +160,11 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
             pc_rotate_priority(A, b + 1);
             pc_wait_for(seq_ready, b + 1);
             const int t0 = b * kTU;
-            double uv[kTU * UD], xv[kTU], yv[kTU];
+            float zv[kTU * UD];
+            double xv[kTU], yv[kTU];
             if constexpr (MODE == MODE_FUSED) {
-                static_for<kTU * UD>([&](auto RR) {
-                    constexpr int r = decltype(RR)::value;
-                    if constexpr (R3Shared<MODEL>::kStageNoise) {
-                        constexpr int d = r % UD;
-                        double v = (double)sh.zs[b & 1][r][lane] * A.sigma + sh.nom[t0 * UD + r];   // as pc_produce*
-                        v = clampd(v, arg5<d>(A.umin), arg5<d>(A.umax));
-                        if constexpr (FB && d == 2) {
-                            if (A.steer_off) v = 0.0;
-                        }
-                        uv[r] = v;
-                    } else {
-                        uv[r] = sh.us[b & 1][r][lane];
-                    }
-                });
+#pragma unroll
+                for (int r = 0; r < kTU * UD; ++r) zv[r] = sh.zs[b & 1][r][lane];
             }
             if constexpr (MODE != MODE_COST) {
 #pragma unroll
@@ -190,7 +181,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
                 static_for<kTU * UD>([&](auto RR) {
                     constexpr int r = decltype(RR)::value;
                     // rows are padded to a multiple of 64 samples (pitch): lanes past K write their padding slot
-                    if (r < nrows) A.u[(size_t)(t0 * UD + r) * pitch + k] = uv[r];
+                    if (r < nrows) A.z[(size_t)(t0 * UD + r) * pitch + k] = zv[r];
                 });
             }
             if constexpr (MODE != MODE_COST) {
@@ -215,7 +206,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
     if constexpr (COST) {
         using Rows = UpdRowsT<kR3RB, kR3Waves>;
         const int R = (H - 1) * udim_of(MODEL);
-        double upd[kUpdCH];
+        UpdT<MODE> upd[kUpdCH];
         const Rows rows{R, wv};
         const int mcount = A.fuse_update ? rows.count() : 0;
         sh.cost[wv][lane] = cost;
@@ -233,7 +224,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
         if (A.fuse_update) {
             // p, ab, c are dead (the loop's last barrier): a private transpose buffer per wave
             double* buf = &sh.p[0][0][0][0] + wv * (kR3RB * (kPcSamples + 1));
-            pc_reduce_rows<kR3RB>(A, buf, upd, rows, mcount, wgt, lane, kk);
+            pc_reduce_rows<kR3RB, MODEL>(A, sh, buf, upd, rows, mcount, wgt, lane, kk);
             if (wv == kR3Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
         }
     }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
     // ---------------- weights and this wave's share of the update (dd:216-237)
     using Rows = UpdRowsT<kTU * udim_of(MODEL), 1>;
     const int R = (H - 1) * udim_of(MODEL);
-    double upd[kUpdCH];
+    UpdT<MODE> upd[kUpdCH];
     const Rows rows{R, 0};
     const int mcount = A.fuse_update ? rows.count() : 0;
     if (mcount > 0) pc_update_fetch(A, upd, rows, 0, mcount, kk);   // (in flight during the exp below)
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
         A.w[k] = wgt;
     }
     if (A.fuse_update) {
-        pc_reduce_rows<kUpdRB>(A, &sh.p[0][0][0][0], upd, rows, mcount, wgt, lane, kk);
+        pc_reduce_rows<kUpdRB, MODEL>(A, sh, &sh.p[0][0][0][0], upd, rows, mcount, wgt, lane, kk);
         pc_block_stats(A, R, wgt, total, live, lane);
     }
 }
