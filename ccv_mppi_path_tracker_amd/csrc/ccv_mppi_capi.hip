@@ -39,6 +39,7 @@ struct ccv_mppi_handle {
     bool fin_pending = false;
     FinalizeArgs fin_args{};
     double* d_u = nullptr;
+    void* d_arena = nullptr;           // one allocation behind u, z, xs, ys, cost, w, partial (2 MB-aligned pieces)
     float* d_z = nullptr;              // the fused iteration stores the normals in place of the controls (mppi_kernels.h)
     double* d_nom_used = nullptr;      // ... and the warm start they were drawn around
     bool controls_in_z = false;        // d_u is stale: the controls of the last iteration are (d_z, d_nom_used)
@@ -699,16 +700,35 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipStreamCreate", e);
     h->stream = h->own_stream;
     const size_t P = (size_t)h->pitch;
+    // The large arrays are pieces of ONE allocation, each starting on a 2 MB boundary.  Separate hipMalloc calls gave, in
+    // some processes (and for some handles of a process), placements with which the steering kernel ran 15 % slower for the
+    // whole life of the handle (51 vs 59 us, tools/bimodal_probe.py) -- one mapping, one set of large page fragments.
+    const size_t nparts_max = (size_t)(h->nblocks > h->nchunks ? h->nblocks : h->nchunks);
+    struct Piece { void** p; size_t bytes; } pieces[] = {
+        {(void**)&h->d_z, (size_t)h->R * P * sizeof(float)},
+        {(void**)&h->d_xs, (size_t)h->H * P * sizeof(double)},
+        {(void**)&h->d_ys, (size_t)h->H * P * sizeof(double)},
+        {(void**)&h->d_u, (size_t)h->R * P * sizeof(double)},
+        {(void**)&h->d_cost, P * sizeof(double)},
+        {(void**)&h->d_w, P * sizeof(double)},
+        {(void**)&h->d_partial, (size_t)(h->R + 1) * nparts_max * sizeof(double)},
+    };
+    constexpr size_t kPieceAlign = (size_t)2 << 20;
+    size_t arena_bytes = 0;
+    for (const Piece& pc : pieces) arena_bytes += (pc.bytes + kPieceAlign - 1) / kPieceAlign * kPieceAlign;
+    if ((e = hipMalloc(&h->d_arena, arena_bytes)) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
+    if ((e = hipMemset(h->d_arena, 0, arena_bytes)) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipMemset", e);
+    {
+        size_t at = 0;
+        for (const Piece& pc : pieces) {
+            *pc.p = static_cast<char*>(h->d_arena) + at;
+            at += (pc.bytes + kPieceAlign - 1) / kPieceAlign * kPieceAlign;
+        }
+    }
     struct { double** p; size_t n; } allocs[] = {
         {&h->d_nominal, (size_t)(CCV_MPPI_MAX_HORIZON + 8) * CCV_MPPI_MAX_UDIM},   // padded: read 4 at a time
         {&h->d_nom_used, (size_t)(CCV_MPPI_MAX_HORIZON + 8) * CCV_MPPI_MAX_UDIM},
-        {&h->d_u, (size_t)h->R * P},
-        {&h->d_xs, (size_t)h->H * P},
-        {&h->d_ys, (size_t)h->H * P},
-        {&h->d_cost, P},
-        {&h->d_w, P},
-        {&h->d_partial, (size_t)(h->R + 1) * (h->nblocks > h->nchunks ? h->nblocks : h->nchunks)},
-        {&h->d_statpart, (size_t)(h->nblocks > h->nchunks ? h->nblocks : h->nchunks) * 3},
+        {&h->d_statpart, nparts_max * 3},
         {&h->d_vec, (size_t)h->R + 1},
         {&h->d_stats, 4},
         {&h->d_cmin, 1},
@@ -717,8 +737,6 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
         if ((e = hipMalloc(a.p, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
         if ((e = hipMemset(*a.p, 0, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipMemset", e);
     }
-    if ((e = hipMalloc(&h->d_z, (size_t)h->R * P * sizeof(float))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
-    if ((e = hipMemset(h->d_z, 0, (size_t)h->R * P * sizeof(float))) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipMemset", e);
 #if defined(CCV_STAMP)
     if ((e = hipMalloc(&h->d_dbg, (64 + 6 * 4096) * sizeof(unsigned long long))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
 #endif
@@ -745,8 +763,8 @@ int ccv_mppi_destroy(ccv_mppi_handle* h) {
     for (hipEvent_t e : h->throttle_ev)
         if (e) (void)hipEventDestroy(e);
     exchange_release(h);
-    void* bufs[] = {h->d_nominal, h->d_u, h->d_xs, h->d_ys, h->d_cost, h->d_w, h->d_partial, h->d_statpart, h->d_vec, h->d_stats,
-                    h->d_cmin, h->d_scratch, h->d_frame, h->d_path, h->d_trace, h->d_dbg, h->d_z, h->d_nom_used};
+    void* bufs[] = {h->d_arena, h->d_nominal, h->d_nom_used, h->d_statpart, h->d_vec, h->d_stats,
+                    h->d_cmin, h->d_scratch, h->d_frame, h->d_path, h->d_trace, h->d_dbg};   // (u, z, xs, ys, cost, w, partial: the arena)
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
