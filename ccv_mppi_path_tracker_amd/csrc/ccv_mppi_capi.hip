@@ -700,9 +700,8 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipStreamCreate", e);
     h->stream = h->own_stream;
     const size_t P = (size_t)h->pitch;
-    // The large arrays are pieces of ONE allocation, each starting on a 2 MB boundary.  Separate hipMalloc calls gave, in
-    // some processes (and for some handles of a process), placements with which the steering kernel ran 15 % slower for the
-    // whole life of the handle (51 vs 59 us, tools/bimodal_probe.py) -- one mapping, one set of large page fragments.
+    // The large arrays are pieces of ONE allocation, each starting on a 2 MB boundary: one mapping, one set of large page
+    // fragments, seven allocator calls less per handle.
     const size_t nparts_max = (size_t)(h->nblocks > h->nchunks ? h->nblocks : h->nchunks);
     struct Piece { void** p; size_t bytes; } pieces[] = {
         {(void**)&h->d_z, (size_t)h->R * P * sizeof(float)},
