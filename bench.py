@@ -160,7 +160,8 @@ def cpu_baseline_threads(w, threads, budget_s=6.0):
 
 def closed_loop_leg(amd, torch, ctl, w, seed, warm=64, ticks=512):
     """SURVEY.md 8(d) asks for the closed loop: the device-resident tick (plant + get_CurrentIndex + calc_RefPath +
-    iteration, three launches, no host data: ccv_mppi_resident_step_enqueue), `ticks` of them back to back after `warm`,
+    iteration, two launches per tick -- the rollout kernel, and the update fused with the next tick's prologue -- no host data:
+    ccv_mppi_resident_step_enqueue), `ticks` of them back to back after `warm`,
     pose fed back every tick, on the workload's own path with the course extended so that it does not end."""
     p = w.params
     need = (warm + ticks + 8) * max(abs(p.u_max[0]), abs(p.u_min[0])) * p.dt + 2.0 * p.horizon * p.v_ref * p.dt
@@ -421,7 +422,9 @@ def main():
         roll_avg_s = roll_us / max(n_ev, 1) * 1e-6
         iter_avg_s = iter_us / max(n_ev, 1) * 1e-6
         achieved = B_roll * k_local / roll_avg_s / 1e9 if roll_avg_s > 0 else None
-        traffic = latest_pmc_traffic(args.workload) if world == 1 else None
+        # the committed PMC pass is of the workload's own launch (its K, its kernel): no figure for any other launch
+        pmc_applies = world == 1 and k_local == w.params.num_samples and args.dt is None and not args.no_state_store
+        traffic = latest_pmc_traffic(args.workload) if pmc_applies else None
         out = {
             # BASELINE.json's metric string; `value` is its first component, `ms_per_step` the second (ms per MPPI iteration)
             "metric": "trajectory rollouts/s (K\u00d7iters/s) + ms/MPPI-iteration, diff-drive T=50" if args.workload == "C2"
