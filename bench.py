@@ -40,16 +40,16 @@ def algorithmic_bytes(T, udim):
 
 def rollout_kernel_name(model, k_local, device):
     """The kernel ccv_mppi_create selects (csrc/ccv_mppi_capi.hip): more blocks of 64 samples than four per CU -> one wave
-    per block (k_rollout_solo); else the three-wave kernel, or the two-wave one for full body."""
+    per block (k_rollout_solo); else the four-wave kernel, or the two-wave one for full body."""
     forced = os.environ.get("CCV_MPPI_KERNEL")
     if forced:
         return {"v1": "k_rollout_cost", "pc": "k_rollout_pc", "r3": "k_rollout_pc" if model == "full_body" else "k_rollout_r3",
-                "solo": "k_rollout_solo"}.get(forced, forced)
+                "r4": "k_rollout_pc" if model == "full_body" else "k_rollout_r4", "solo": "k_rollout_solo"}.get(forced, forced)
     import torch
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     if (k_local + 63) // 64 > 4 * cus:
         return "k_rollout_solo"
-    return "k_rollout_pc" if model == "full_body" else "k_rollout_r3"
+    return "k_rollout_pc" if model == "full_body" else "k_rollout_r4"
 
 
 def device_copy_gbs(torch, nbytes=1 << 30, reps=10):

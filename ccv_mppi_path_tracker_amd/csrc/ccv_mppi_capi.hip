@@ -20,6 +20,7 @@
 #include "mppi_kernels.h"
 #include "mppi_rollout_pc.h"
 #include "mppi_rollout_r3.h"
+#include "mppi_rollout_r4.h"
 #include "mppi_rollout_solo.h"
 #include "mppi_resident.h"
 
@@ -232,6 +233,19 @@ void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const 
         return;
     }
     if constexpr (MODEL != CCV_MPPI_FULL_BODY) {
+    if (h->coop == 3) {
+        // four-wave kernel (mppi_rollout_r4.h)
+        const dim3 cgrid((h->K + kPcSamples - 1) / kPcSamples), cblock(kR4Waves * 64);
+        if (mode == MODE_FUSED && h->ev_kernel_start) {
+            hipExtLaunchKernelGGL((k_rollout_r4<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, h->ev_kernel_start,
+                                  h->ev_kernel_stop, 0, A, W);
+            return;
+        }
+        if (mode == MODE_FUSED) hipLaunchKernelGGL((k_rollout_r4<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, A, W);
+        else if (mode == MODE_ROLLOUT) hipLaunchKernelGGL((k_rollout_r4<MODEL, MODE_ROLLOUT>), cgrid, cblock, 0, h->stream, A, W);
+        else hipLaunchKernelGGL((k_rollout_r4<MODEL, MODE_COST>), cgrid, cblock, 0, h->stream, A, W);
+        return;
+    }
     if (h->coop == 2) {
         // three-wave kernel (mppi_rollout_r3.h); not built for full body (see ccv_mppi_create)
         const dim3 cgrid((h->K + kPcSamples - 1) / kPcSamples), cblock(kR3Waves * 64);
@@ -659,11 +673,12 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     h->lds_window = !(env && std::strcmp(env, "scalar") == 0);
     const char* kenv = getenv("CCV_MPPI_KERNEL");
     h->coop = !(kenv && std::strcmp(kenv, "v1") == 0) && h->lds_window;
-    // diff-drive, steering: the three-wave kernel with a store wave.  Full body keeps the two-wave kernel: its producer
-    // needs 250 VGPR (three waves per SIMD allow 168) and its staging would not fit four workgroups per CU.
-    // CCV_MPPI_KERNEL=pc / r3 force one or the other where built (experiments)
-    if (h->coop && h->cfg.model != CCV_MPPI_FULL_BODY) h->coop = 2;
-    if (h->coop && kenv && std::strcmp(kenv, "r3") == 0) h->coop = 2;
+    // diff-drive, steering: the four-wave kernel (noise / dynamics / distance / store wave, mppi_rollout_r4.h; round 2: -6 %
+    // against the three-wave kernel at C2 and, unlike it, the same time in every process at C3).  Full body keeps the
+    // two-wave kernel: its producer needs 250 VGPR (four waves per SIMD allow 128).
+    // CCV_MPPI_KERNEL=pc / r3 / r4 force one where built (experiments, tests)
+    if (h->coop && h->cfg.model != CCV_MPPI_FULL_BODY) h->coop = 3;
+    if (h->coop && kenv && std::strcmp(kenv, "r3") == 0 && h->cfg.model != CCV_MPPI_FULL_BODY) h->coop = 2;
     if (h->coop && kenv && std::strcmp(kenv, "pc") == 0) h->coop = 1;
     // More blocks of 64 samples than the multi-wave kernels can hold at once (4 workgroups per CU): one wave does
     // everything for its samples (mppi_rollout_solo.h) -- the SIMDs are kept busy by independent waves then, and the
@@ -677,8 +692,11 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
         h->solo = h->coop && !kenv && h->nblocks > 4 * cus;
         if (h->coop && kenv && std::strcmp(kenv, "solo") == 0) h->solo = true;
     }
-    h->prio_rotate = h->coop ? 1 : 0;   // measured: -4 us on the three-wave kernel (C2), -3 % on the two-wave one (C4)
-    if (const char* pv = std::getenv("CCV_MPPI_PRIO")) h->prio_rotate = std::strcmp(pv, "0") != 0;
+    // wave priorities (pc_rotate_priority): measured -4 us on the three-wave kernel (C2), -3 % on the two-wave one (C4), and
+    // with four levels -5 us on the four-wave kernel (43.4 -> 38.3 us at C2)
+    h->prio_rotate = h->coop == 3 ? 2 : h->coop ? 1 : 0;
+    if (const char* pv = std::getenv("CCV_MPPI_PRIO")) h->prio_rotate = std::atoi(pv) != 0 ? h->prio_rotate : 0;
+
     // Exact window pruning in the distance loop (pc_prune_window).  Measured on one box, kernel us off -> on: diff drive
     // K = 65 536 49.0 -> 42.7, steering 61.7 -> 57.3 (three-wave kernels).  CCV_MPPI_PRUNE=0/1 forces it (experiments;
     // results do not depend on it, tested).

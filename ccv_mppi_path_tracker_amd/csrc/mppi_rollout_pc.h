@@ -136,11 +136,25 @@ __device__ __forceinline__ double pc_control_from_normal(const RolloutArgs& A, c
 // workgroups per CU: 26 / 33 / 41 / 45 us for the same work, and the kernel ends with the slowest.  Alternating which
 // half of a CU's workgroups is favoured, once per time block, evens them out (28 / 33 / 39 / 40 us; kernel -4 us).
 // rank = position of the workgroup in its CU's dispatch order (workgroups go round-robin over the CUs).
+__device__ __forceinline__ void pc_set_priority(const int p) {   // (s_setprio takes an immediate)
+    switch (p) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+// prio_rotate 1: two levels, alternating halves (two- and three-wave kernels); 2: four levels, level = (rank + s) mod 4 (the
+// four-wave kernel, mppi_rollout_r4.h: its waves call this with s = time block + role)
 __device__ __forceinline__ void pc_rotate_priority(const RolloutArgs& A, const int s) {
     if (!A.prio_rotate) return;
     const int rank = (int)blockIdx.x / A.cu_count;
-    if ((rank ^ s) & 1) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
+    if (A.prio_rotate == 1) {
+        if ((rank ^ s) & 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    } else {
+        pc_set_priority((rank + s) & 3);
+    }
 }
 
 // LDS sequence numbers for hand-offs without a barrier (mppi_rollout_r3.h): written by one wave, polled by another.  The
@@ -353,7 +367,8 @@ __device__ __forceinline__ void pc_noise_ahead(const RolloutArgs& A, float (*slo
 // batches so that the independent chains of the 8 steps (Philox rounds, Box-Muller, sin/cos) sit in ONE basic block and
 // interleave -- a lone wave then issues back to back instead of waiting out each chain's latency.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODEL, int MODE, class SH>
+// ZLDS (four-wave kernel): the block's normals are already in sh.zs, made by the noise wave.
+template <int MODEL, int MODE, class SH, bool ZLDS = false>
 __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh, PcState<MODEL>& S, double& cost,
                                                    const int b, const int lane, const int k, const int kk, const bool live,
                                                    const uint32_t kg
@@ -382,7 +397,10 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
 #pragma unroll
             for (int i = 0; i < 4 * CN; ++i) nomv[i] = sh.nom[t0 * UD + 4 * C0 + i];
             CCV_KEEP_ORDER();
-            if (from_lds) {
+            if constexpr (ZLDS) {
+#pragma unroll
+                for (int i = 0; i < 4 * CN; ++i) z[i] = sh.zs[b & 1][4 * C0 + i][lane];
+            } else if (from_lds) {
 #pragma unroll
                 for (int i = 0; i < 4 * CN; ++i) z[i] = ahead[4 * C0 + i][lane];
             } else {
@@ -400,7 +418,8 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
                 }
                 u[tt][d] = v;
                 if constexpr (SH::kStage) {
-                    if constexpr (SH::kStageNoise) sh.zs[b & 1][nloc][lane] = z[i];
+                    if constexpr (ZLDS) {
+                    } else if constexpr (SH::kStageNoise) sh.zs[b & 1][nloc][lane] = z[i];
                     else sh.us[b & 1][nloc][lane] = v;
                 } else {
 #if !defined(CCV_ABL_NO_STORE)
@@ -743,7 +762,9 @@ __device__ __forceinline__ void pc_prune_window(const RolloutArgs& A, const SH& 
 // Straight fp64 FMA/MIN; four window points per iteration so the LDS broadcast reads are covered and the compiler's
 // canonicalising max in front of fmin() is paid once per four minima.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NV, int MODEL, class SH>
+// LEAN (four-wave kernel, 128 VGPRs): two window points per register set instead of four and the running minimum taken
+// point pair by point pair -- 48 registers less; the same minima, hence the same bits.
+template <int NV, int MODEL, class SH, bool LEAN = false>
 __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, double& cost, const int b, const int lane,
                                            const int i0 = 0,          // states i0 .. i0+NV-1 of block b
                                            int* prune_on = nullptr,   // wave-uniform switch of the window pruning (below)
@@ -805,6 +826,34 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
         if (prune_on && 4 * (je - jb) > 3 * H4) *prune_on = 0;
     }
 #endif
+    if constexpr (LEAN) {
+        double2 qa[2], qb[2];
+        double ca[2], cb[2];
+        auto fetch2 = [&](double2(&ab)[2], double(&c)[2], const int j) {
+            ab[0] = sh.ab[j];
+            c[0] = sh.c[j];
+            ab[1] = sh.ab[j + 1];
+            c[1] = sh.c[j + 1];
+        };
+        auto points2 = [&](const double2(&ab)[2], const double(&c)[2]) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const double f0 = fma(ab[0].x, px[i], fma(ab[0].y, py[i], c[0]));
+                const double f1 = fma(ab[1].x, px[i], fma(ab[1].y, py[i], c[1]));
+                const double t = fmin(f0, f1);
+                asm("v_min_f64 %0, %1, %2" : "=v"(m[i]) : "v"(m[i]), "v"(t));
+            }
+        };
+        fetch2(qa, ca, jb);
+        for (int j = jb; j < je; j += 4) {   // (je - jb is a multiple of 4; the read-ahead ends inside the arrays' padding)
+            fetch2(qb, cb, j + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            points2(qa, ca);
+            fetch2(qa, ca, j + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            points2(qb, cb);
+        }
+    } else {
     fetch(ab0, c0, jb);
     for (int j = jb; j < je; j += 8) {   // two register sets in ping-pong: no copies
         fetch(ab1, c1, j + 4);
@@ -814,6 +863,7 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
         fetch(ab0, c0, j + 8);
         __builtin_amdgcn_sched_barrier(0);
         points4(ab1, c1);
+    }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {

@@ -55,16 +55,16 @@ struct R3Shared {
 // First chunk of the epilogue's re-read for this kernel's row dealing (units of kR3RB rows, wave w owns units w, w+3, ...):
 // with the row of load i a compile-time distance from the wave's first row, an address costs one scalar multiply and
 // one vector add instead of the ~12 scalar instructions of the generic clamped form (60 loads per wave: ~1.3 us).
-template <class T>
+template <class T, int RB = kR3RB, int NW = kR3Waves>
 __device__ __forceinline__ void r3_update_fetch0(const RolloutArgs& A, T (&v)[kUpdCH], const int wv, const int mcount,
                                                  const int kk) {
     const size_t pitch = (size_t)A.pitch;
     const T* p0;
-    if constexpr (std::is_same<T, float>::value) p0 = A.z + kk + (size_t)(wv * kR3RB) * pitch;   // fused: the normals
-    else p0 = A.u + kk + (size_t)(wv * kR3RB) * pitch;
+    if constexpr (std::is_same<T, float>::value) p0 = A.z + kk + (size_t)(wv * RB) * pitch;   // fused: the normals
+    else p0 = A.u + kk + (size_t)(wv * RB) * pitch;
 #pragma unroll
     for (int i = 0; i < kUpdCH; ++i) {
-        const size_t rows_ahead = (size_t)((i / kR3RB) * (kR3Waves * kR3RB) + i % kR3RB);   // constant after unrolling
+        const size_t rows_ahead = (size_t)((i / RB) * (NW * RB) + i % RB);   // constant after unrolling
         v[i] = 0;
         if (i < mcount) v[i] = p0[rows_ahead * pitch];
     }

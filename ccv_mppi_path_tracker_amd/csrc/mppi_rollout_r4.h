@@ -1,0 +1,312 @@
+// Four-wave rollout kernel for gfx950 (MI355X): one workgroup = 64 samples = noise wave + dynamics wave + distance wave +
+// store wave.
+//
+// Why a fourth wave.  At K = 65 536 the three-wave kernel (mppi_rollout_r3.h) puts three waves on every SIMD, one of each
+// role, and the SIMD's vector unit is busy for little more than half of the kernel time: every wave is a long dependent
+// chain that waits out its own latencies, three of them do not cover each other, and a workgroup advances at the pace of
+// its longest chain -- the producer, ~3.6 k issue cycles per block of 8 steps, half of them the Philox / Box-Muller noise
+// that nothing in the block depends on but the controls' first operation.  Here the producer is cut in two:
+//
+//   wave 0 (noise)      the fp32 normals of time block b (Philox4x32-10 + Box-Muller: integer / fp32 work only) -> LDS
+//   wave 1 (dynamics)   controls from the normals, dynamics and control costs of block b-1; (x, y) -> LDS
+//   wave 2 (distance)   min over the window points of the squared distance for the states of block b-2
+//   wave 3 (store)      normals and states of block b-2: LDS -> HBM
+//
+// so that the longest chain of a workgroup is ~2.5 k cycles per block, and with four waves per workgroup a SIMD holds four
+// waves (128 VGPRs each).  The hardware deals the waves of consecutive workgroups to the SIMDs of a CU in a fixed rotation
+// (tools/microbench/wave_placement.hip: with four workgroups of four waves per CU every SIMD receives wave 0, 1, 2 and 3 of
+// four different workgroups), so every SIMD again runs one wave of each role.
+// Hand-offs are LDS sequence numbers as in the three-wave kernel.  Arithmetic, noise and the summation order inside a row
+// are those of k_rollout_pc / k_rollout_r3: the results are bit-identical.
+#pragma once
+#include "mppi_rollout_r3.h"
+
+namespace ccv {
+
+constexpr int kR4Waves = 4;
+constexpr int kR4RB = 12;   // rows per LDS transpose batch in the epilogue (6: +1.4 us at C2)
+
+// The control rows of the epilogue, dealt to the four waves as contiguous ranges (first row a multiple of u_dim, so that a
+// row's control dimension is a compile-time function of its position in the range: pc_reduce_rows).
+//   waves 0, 1 (noise, dynamics)   the rows of all time blocks but the last three, half each: these waves are through their
+//                                  loops one to two block times before the workgroup is, the rows have long been stored, and
+//                                  their re-read is ISSUED BEFORE the kernel's barrier -- its latency (most of these rows
+//                                  have left the L2 by then) passes while the distance and the store wave finish
+//   waves 2, 3 (distance, store)   the rows of the last three blocks, half each, read after the barrier (L2 hits)
+struct R4Rows {
+    static constexpr int BR = 60;   // (what pc_reduce_rows asserts: ranges start at multiples of 2, 3 and 5)
+    int first, n;
+    __device__ __forceinline__ int count() const { return n; }
+    __device__ __forceinline__ int row(const int m) const { return first + m; }
+};
+template <int UD>
+__device__ __forceinline__ R4Rows r4_rows(const int H, const int nblocks, const int wv, int& nb_early) {
+    const int R = (H - 1) * UD;
+    nb_early = max(0, nblocks - 3);
+    const int r_early = min(R, nb_early * kTU * UD);
+    const int half_e = ((r_early / UD + 1) / 2) * UD, half_l = (((R - r_early) / UD + 1) / 2) * UD;
+    switch (wv) {
+        case 0: return R4Rows{0, half_e};
+        case 1: return R4Rows{half_e, r_early - half_e};
+        case 2: return R4Rows{r_early, half_l};
+        default: return R4Rows{r_early + half_l, R - r_early - half_l};
+    }
+}
+// first chunk of a range: row i of the chunk is i rows past the range's first one (one scalar add per address)
+template <class T>
+__device__ __forceinline__ void r4_fetch0(const RolloutArgs& A, T (&v)[kUpdCH], const R4Rows& rows, const int kk) {
+    const size_t pitch = (size_t)A.pitch;
+    const T* p0;
+    if constexpr (std::is_same<T, float>::value) p0 = A.z + kk + (size_t)rows.first * pitch;   // fused: the normals
+    else p0 = A.u + kk + (size_t)rows.first * pitch;
+#pragma unroll
+    for (int i = 0; i < kUpdCH; ++i) {
+        v[i] = 0;
+        if (i < rows.n) v[i] = p0[(size_t)i * pitch];
+    }
+}
+
+template <int MODEL>
+struct R4Shared {
+    static constexpr bool kStage = true;
+    static constexpr bool kStageNoise = true;
+    static constexpr int kPBuf = 2;
+    // (p, ab, c, zs are contiguous and are reused as the epilogue's transpose buffers)
+    double p[2][kTU][2][kPcSamples];                       // absolute (x,y) of the 8 states of a block, double buffered
+    double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
+    double c[kMaxH + 4];
+    float zs[2][kTU * udim_of(MODEL)][kPcSamples];         // normals of a block, double buffered
+    double cost[kR4Waves][kPcSamples];
+    alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u*
+    double us[1][1][kPcSamples];                           // (unused: the building blocks name it)
+    // hand-off sequence numbers: [0] blocks whose normals are in LDS, [1] blocks whose states are in LDS, [2] / [3] blocks the
+    // distance / store wave has taken into registers, [4] blocks whose stores to HBM are all acknowledged
+    int seq[8];
+};
+
+template <int MODEL, int MODE>
+__global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutArgs Ak, const Window Wk) {
+    constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
+    constexpr bool COST = MODE != MODE_ROLLOUT;
+    constexpr int UD = udim_of(MODEL);
+    static_assert(!FB, "diff drive and steering only");
+    __shared__ R4Shared<MODEL> sh;
+    static_assert(offsetof(R4Shared<MODEL>, zs) + sizeof(sh.zs) >= kR4Waves * kR4RB * (kPcSamples + 1) * sizeof(double), "epilogue buffers");
+    const RolloutArgs A = with_resident_pose(Ak);
+    const int H = A.H;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (COST) stage_window(A, Wk, sh, kR4Waves * 64);
+    if constexpr (MODE == MODE_FUSED) pc_stage_nominal<MODEL>(A, sh, kR4Waves * 64);
+    const int k = blockIdx.x * kPcSamples + lane;
+    const bool live = k < A.K;
+    const int kk = live ? k : A.K - 1;
+    const uint32_t kg = (uint32_t)(A.k_offset + kk);
+    double cost = 0.0;
+    const int nblocks = (H + kTU - 1) / kTU;
+    const int nstates = H;   // states that reach the path cost (dd:199)
+    // blocks whose 8 steps all carry controls: their normals come from the noise wave (the last, partial block is the
+    // dynamics wave's own: pc_produce)
+    const int nfull = MODE == MODE_FUSED ? (H - 1) / kTU : 0;
+    if (threadIdx.x < 8) sh.seq[threadIdx.x] = 0;
+    __syncthreads();
+    int* const seq_noise = &sh.seq[0];
+    int* const seq_ready = &sh.seq[1];
+    int* const seq_dist = &sh.seq[2];
+    int* const seq_store = &sh.seq[3];
+    int* const seq_stored = &sh.seq[4];
+    // the epilogue's rows of this wave (see R4Rows)
+    int nb_early;
+    R4Rows rows = r4_rows<UD>(H, nblocks, wv, nb_early);
+    if (!(COST && A.fuse_update)) rows.n = 0;
+    UpdT<MODE> upd[kUpdCH];
+    auto early_fetch = [&]() {
+        if constexpr (MODE == MODE_FUSED) {   // (stage-wise cost call: fp64 controls, 120 registers -- fetched after the barrier)
+            if (rows.n > 0) {
+                pc_wait_for(seq_stored, nb_early);   // the rows are in HBM / L2
+                r4_fetch0(A, upd, rows, kk);
+            }
+        }
+    };
+    if (wv == 0) {
+        // ---------------- noise wave
+        if constexpr (MODE == MODE_FUSED) {
+            constexpr int NCALL = kTU * UD / 4;
+            for (int b = 0; b < nfull; ++b) {
+                pc_rotate_priority(A, b);
+                if (b >= 2) {   // zs[b & 1] last held block b-2: the dynamics wave is through it, the store wave has loaded it
+                    pc_wait_for(seq_ready, b - 1);
+                    pc_wait_for(seq_store, b - 1);
+                }
+                // the same grouping of the Philox calls as pc_produce_batched (4 | 3 + 3): a normal does not depend on it
+                auto group = [&](auto C0_, auto CN_) {
+                    constexpr int C0 = decltype(C0_)::value, CN = decltype(CN_)::value;
+                    float z[4 * CN];
+                    pc_block_normals<MODEL, C0, CN>(A, b, kg, z);
+#pragma unroll
+                    for (int i = 0; i < 4 * CN; ++i) sh.zs[b & 1][4 * C0 + i][lane] = z[i];
+                };
+                using std::integral_constant;
+                if constexpr (NCALL == 4) {
+                    group(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+                } else {
+                    static_assert(NCALL == 6, "steering: 3 + 3 Philox calls");
+                    group(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+                    group(integral_constant<int, 3>{}, integral_constant<int, 3>{});
+                }
+                pc_publish(seq_noise, b + 1);
+            }
+        }
+        if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
+        early_fetch();
+    } else if (wv == 1) {
+        // ---------------- dynamics wave: all time blocks, state in registers
+        PcState<MODEL> S;
+        S.x = A.x0[0];
+        S.y = A.x0[1];
+        S.yaw = A.x0[2];
+        S.roll = A.x0[3];
+        S.pitch = A.x0[4];
+        S.p_v = S.p_rv = S.p_sdir = S.p_c2 = S.p_c3 = S.p_ac = 0.0;
+        S.p_cdir = 1.0;
+        fast_sincos(A.x0[2], S.sn, S.cs);
+#if defined(CCV_STAMP)
+        PcStamps ST;
+        for (int i = 0; i < 8; ++i) ST.acc[i] = 0;
+        ST.last = 0;
+#endif
+        for (int b = 0; b < nblocks; ++b) {
+            pc_rotate_priority(A, b + 1);
+            if (b >= 2) {   // the buffers of block b last held block b-2: both readers must have taken it
+                pc_wait_for(seq_dist, b - 1);
+                pc_wait_for(seq_store, b - 1);
+            }
+            if (b < nfull) {
+                pc_wait_for(seq_noise, b + 1);
+                pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true>(A, sh, S, cost, b, lane, k, kk, live, kg
+#if defined(CCV_STAMP)
+                                                                     , ST
+#endif
+                );
+            } else {
+                bool done = false;
+                if (MODE != MODE_FUSED && b * kTU + kTU <= H - 1)
+                    done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg
+#if defined(CCV_STAMP)
+                                                           , ST
+#endif
+                    );
+                if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
+            }
+            pc_publish(seq_ready, b + 1);
+        }
+        if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
+        early_fetch();
+    } else if (wv == 2) {
+        // ---------------- distance wave: the states of block b as soon as the dynamics wave has published it
+        int prune_on = 1;
+        for (int b = 0; b < nblocks; ++b) {
+            pc_rotate_priority(A, b + 2);
+            pc_wait_for(seq_ready, b + 1);
+            bool taken = false;
+            if constexpr (COST) {
+                const int nv = min(kR3CStates, nstates - b * kTU);
+                taken = nv > 0;
+                switch (nv) {
+                    case 8: pc_consume<8, MODEL, R4Shared<MODEL>, true>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 7: pc_consume<7, MODEL, R4Shared<MODEL>, true>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 6: pc_consume<6, MODEL, R4Shared<MODEL>, true>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 5: pc_consume<5, MODEL, R4Shared<MODEL>, true>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 4: pc_consume<4, MODEL, R4Shared<MODEL>, true>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 3: pc_consume<3, MODEL, R4Shared<MODEL>, true>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 2: pc_consume<2, MODEL, R4Shared<MODEL>, true>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    case 1: pc_consume<1, MODEL, R4Shared<MODEL>, true>(A, sh, cost, b, lane, 0, &prune_on, seq_dist, b + 1); break;
+                    default: break;
+                }
+            }
+            if (!taken) pc_publish(seq_dist, b + 1);   // (nothing of this block reaches the path cost)
+        }
+    } else {
+        // ---------------- store wave: normals (MODE_FUSED) and states (not in MODE_COST) of block b, LDS -> registers ->
+        // HBM.  Everything is read from LDS first and the buffer handed back before the first store issues.
+        const size_t pitch = (size_t)A.pitch;
+        for (int b = 0; b < nblocks; ++b) {
+            pc_rotate_priority(A, b + 3);
+            pc_wait_for(seq_ready, b + 1);
+            const int t0 = b * kTU;
+            float zv[kTU * UD];
+            double xv[kTU], yv[kTU];
+            if constexpr (MODE == MODE_FUSED) {
+#pragma unroll
+                for (int r = 0; r < kTU * UD; ++r) zv[r] = sh.zs[b & 1][r][lane];
+            }
+            if constexpr (MODE != MODE_COST) {
+#pragma unroll
+                for (int tt = 0; tt < kTU; ++tt) {
+                    xv[tt] = sh.p[b & 1][tt][0][lane];
+                    yv[tt] = sh.p[b & 1][tt][1][lane];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pc_publish(seq_store, b + 1);
+#if !defined(CCV_ABL_NO_STORE)
+            if constexpr (MODE == MODE_FUSED) {
+                const int nrows = min(kTU, H - 1 - t0) * UD;   // control steps t < H-1
+                static_for<kTU * UD>([&](auto RR) {
+                    constexpr int r = decltype(RR)::value;
+                    // rows are padded to a multiple of 64 samples (pitch): lanes past K write their padding slot
+                    if (r < nrows) A.z[(size_t)(t0 * UD + r) * pitch + k] = zv[r];
+                });
+            }
+            if constexpr (MODE != MODE_COST) {
+                if (A.store_xy) {
+                    const int nst = min(kTU, H - t0);           // states t < H
+#pragma unroll
+                    for (int tt = 0; tt < kTU; ++tt) {
+                        if (tt < nst) {
+                            CCV_STATE_STORE(&A.xs[(size_t)(t0 + tt) * pitch + k], xv[tt]);
+                            CCV_STATE_STORE(&A.ys[(size_t)(t0 + tt) * pitch + k], yv[tt]);
+                        }
+                    }
+                }
+            }
+#endif
+            if constexpr (MODE == MODE_FUSED) {
+                // all stores of the blocks before this one are acknowledged once no more than this block's own are
+                // outstanding (vector-memory operations complete in order); a partial block waits for everything
+                constexpr int kRowsZ = kTU * UD, kRowsAll = kTU * UD + 2 * kTU;
+                static_assert(kRowsAll <= 63, "vmcnt is a 6-bit counter");
+                if (t0 + kTU <= H - 1 && A.store_xy) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowsAll) : "memory");
+                else if (t0 + kTU <= H - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowsZ) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pc_publish(seq_stored, b);
+            }
+        }
+        // the other waves re-read the rows of normals in the epilogue: all of this wave's stores are acknowledged before the
+        // barrier below
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
+    if constexpr (COST) {
+        const int R = (H - 1) * UD;
+        const int mcount = rows.n;
+        sh.cost[wv][lane] = cost;
+        // the one barrier of the kernel: every wave is through its loop (the store wave with all its stores acknowledged),
+        // the cost parts are in LDS, and p / ab / c / zs are dead
+        pc_barrier_lds();
+        if ((MODE != MODE_FUSED || wv >= 2) && mcount > 0) r4_fetch0(A, upd, rows, kk);
+        const double total = ((sh.cost[0][lane] + sh.cost[1][lane]) + sh.cost[2][lane]) + sh.cost[3][lane];
+        const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
+        if (wv == 0 && live) {
+            A.cost[k] = total;
+            A.w[k] = wgt;
+        }
+        if (A.fuse_update) {
+            double* buf = &sh.p[0][0][0][0] + wv * (kR4RB * (kPcSamples + 1));
+            pc_reduce_rows<kR4RB, MODEL>(A, sh, buf, upd, rows, mcount, wgt, lane, kk);
+            if (wv == kR4Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
+        }
+    }
+}
+
+}  // namespace ccv

@@ -201,29 +201,45 @@ def test_kernel_variants_agree(monkeypatch, name):
     np.testing.assert_array_equal(res[1], res[2])
 
 
-@pytest.mark.parametrize("K,H", [(256, 50), (1000, 50), (130, 9), (64, 3), (4097, 128)])
-def test_two_wave_and_three_wave_kernels_agree(monkeypatch, K, H):
-    """Diff-drive runs the three-wave kernel (producer / distance / store wave, mppi_rollout_r3.h) by default; the
-    two-wave kernel (mppi_rollout_pc.h, the one steering / full body use) must give the same samples, states and
-    per-sample costs bit for bit -- same arithmetic, only a different split over waves -- and the same controls up to the
-    order in which the per-wave cost parts are added.  The wave-priority rotation must not change anything."""
-    p = configs.workload("C2").params.with_(num_samples=K, horizon=H)
-    path = helpers.oracle_path("sinusoid")
+@pytest.mark.parametrize("wl,K,H", [("C2", 256, 50), ("C2", 1000, 50), ("C2", 130, 9), ("C2", 64, 3), ("C2", 4097, 128),
+                                    ("C2", 777, 17), ("C2", 640, 25), ("C3", 1000, 50), ("C3", 321, 9), ("C3", 64, 3),
+                                    ("C3", 2049, 128)])
+def test_multi_wave_kernels_agree(monkeypatch, wl, K, H):
+    """Diff-drive and steering run the four-wave kernel (noise / dynamics / distance / store wave, mppi_rollout_r4.h) by
+    default; the three-wave kernel (mppi_rollout_r3.h) splits the same arithmetic over the same cost parts and must give
+    the same bits everywhere -- samples, states, per-sample costs, weights, controls -- over two iterations; the two-wave
+    kernel (mppi_rollout_pc.h, the one full body uses) the same samples and states bit for bit and the same costs and
+    controls up to the order in which the per-wave cost parts and the rows' partial sums are added.  The wave-priority
+    rotation must not change anything.  Horizons with full blocks only, with a one-step tail, shorter than the
+    pipeline is deep."""
+    w = configs.workload(wl)
+    p = w.params.with_(num_samples=K, horizon=H)
+    path = helpers.oracle_path(w.path)
     state = start_state(p, path)
     xr, yr, yaw = helpers.oracle_window(p, path, state)
-    monkeypatch.setenv("CCV_MPPI_KERNEL", "r3")
+    monkeypatch.delenv("CCV_MPPI_KERNEL", raising=False)
     a = MPPIController(p)
     monkeypatch.setenv("CCV_MPPI_PRIO", "0")
     a0 = MPPIController(p)
+    monkeypatch.delenv("CCV_MPPI_PRIO", raising=False)
+    monkeypatch.setenv("CCV_MPPI_KERNEL", "r3")
+    r3 = MPPIController(p)
     monkeypatch.setenv("CCV_MPPI_KERNEL", "pc")
     b = MPPIController(p)
-    res = [g.iterate(state, p.dt, xr, yr, yaw[0], 11, 4, want_stats=False) for g in (a, a0, b)]
-    np.testing.assert_array_equal(res[0], res[1])
+    for it in range(2):   # (the second iteration starts from the first one's update)
+        res = [g.iterate(state, p.dt, xr, yr, yaw[0], 11, 4 + it, want_stats=False) for g in (a, a0, r3, b)]
+        np.testing.assert_array_equal(res[0], res[1])
+        np.testing.assert_array_equal(res[0], res[2])
+        np.testing.assert_allclose(res[0], res[3], rtol=1e-10, atol=1e-13)
     np.testing.assert_array_equal(a.read_costs(), a0.read_costs())
-    np.testing.assert_array_equal(a.read_controls(), b.read_controls())
-    np.testing.assert_array_equal(a.read_candidates(), b.read_candidates())
-    np.testing.assert_allclose(a.read_costs(), b.read_costs(), rtol=1e-14)
-    np.testing.assert_allclose(res[0], res[2], rtol=1e-11, atol=1e-15)
+    np.testing.assert_array_equal(a.read_costs(), r3.read_costs())
+    np.testing.assert_array_equal(a.read_weights(), r3.read_weights())
+    np.testing.assert_array_equal(a.read_controls(), r3.read_controls())
+    np.testing.assert_array_equal(a.read_candidates(), r3.read_candidates())
+    # (second iteration: the warm starts of the two already differ by the summation order of the first update)
+    np.testing.assert_allclose(a.read_controls(), b.read_controls(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(a.read_candidates(), b.read_candidates(), rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(a.read_costs(), b.read_costs(), rtol=1e-10)
 
 
 @pytest.mark.parametrize("wl,K,H", [("C4", 256, 80), ("C4", 1000, 80), ("C4", 130, 9), ("C4", 64, 3), ("C4", 2049, 128),
