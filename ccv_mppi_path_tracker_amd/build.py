@@ -13,7 +13,7 @@ LIBDIR = os.path.join(_PKG, "lib")
 LIB = os.path.join(LIBDIR, "libccv_mppi_hip.so")
 SOURCES = ["ccv_mppi_capi.hip", "ccv_mppi_host.cpp", os.path.join("host", "mppi_node.cpp")]
 DEPS = ["ccv_mppi_capi.hip", "ccv_mppi_host.cpp", os.path.join("host", "mppi_node.cpp"),
-        os.path.join("..", "..", "include", "ccv_mppi_node.hpp"), "mppi_kernels.h", "mppi_rollout_pc.h", "mppi_rollout_r3.h", "mppi_rollout_solo.h", "mppi_resident.h", "fast_trig.h", "noise_spec.h",
+        os.path.join("..", "..", "include", "ccv_mppi_node.hpp"), "mppi_kernels.h", "mppi_rollout_pc.h", "mppi_rollout_r3.h", "mppi_rollout_r4.h", "mppi_rollout_solo.h", "mppi_resident.h", "fast_trig.h", "noise_spec.h",
         os.path.join("..", "..", "include", "ccv_mppi.h"), os.path.join("..", "..", "include", "ccv_mppi_host.h")]
 
 HIPCC_FLAGS = [

@@ -26,6 +26,12 @@ struct Philox4 {
     uint32_t x, y, z, w;
 };
 
+// a ^ b ^ c in one instruction (gfx950: v_bitop3_b32 with the truth table of the 3-input xor; the compiler does not form
+// it by itself): two of them per Philox round instead of four v_xor_b32
+__device__ __forceinline__ uint32_t xor3(const uint32_t a, const uint32_t b, const uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
 __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                  uint32_t k1) {
 #pragma unroll
@@ -33,8 +39,8 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
         // one 32x32->64 multiply per lane pair (v_mad_u64_u32) instead of mul_lo + mul_hi
         const unsigned long long pa = (unsigned long long)c0 * 0xD2511F53ull;
         const unsigned long long pb = (unsigned long long)c2 * 0xCD9E8D57ull;
-        const uint32_t n0 = (uint32_t)(pb >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(pa >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = xor3((uint32_t)(pb >> 32), c1, k0);
+        const uint32_t n2 = xor3((uint32_t)(pa >> 32), c3, k1);
         c1 = (uint32_t)pb;
         c3 = (uint32_t)pa;
         c0 = n0;
@@ -61,8 +67,8 @@ __device__ __forceinline__ void philox4x32_10_n(uint32_t (&c0)[N], uint32_t (&c1
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const uint32_t n0 = (uint32_t)(pb[i] >> 32) ^ c1[i] ^ k0;
-            const uint32_t n2 = (uint32_t)(pa[i] >> 32) ^ c3[i] ^ k1;
+            const uint32_t n0 = xor3((uint32_t)(pb[i] >> 32), c1[i], k0);
+            const uint32_t n2 = xor3((uint32_t)(pa[i] >> 32), c3[i], k1);
             c1[i] = (uint32_t)pb[i];
             c3[i] = (uint32_t)pa[i];
             c0[i] = n0;
@@ -72,6 +78,31 @@ __device__ __forceinline__ void philox4x32_10_n(uint32_t (&c0)[N], uint32_t (&c1
         k1 += 0xBB67AE85u;
         CCV_KEEP_ORDER();
     }
+}
+
+// Correctly rounded sqrt for the radius.  The argument is -2 ln u1 with u1 in [2^-32, 1 - 2^-32], i.e. in [4.6e-10, 44.4]:
+// the generic expansion's scaling of tiny arguments and its zero / infinity test are dead weight there (16 instructions per
+// root).  What is left is its core: the hardware root (within 1 ulp) and the two residual tests that move it to the
+// neighbour where needed -- the same bits as __builtin_sqrtf under -fhip-fp32-correctly-rounded-divide-sqrt, checked for
+// every one of the 2^32 radius words and for every float in [2^-40, 2^7] by tools/microbench/sqrt_check.hip.
+__device__ __forceinline__ float sqrt_cr_radius(const float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float r = r_dn <= 0.0f ? s_dn : s;
+    r = r_up > 0.0f ? s_up : r;
+    return r;
+}
+
+// Quadrant rotation of Box-Muller by sign bits: z0 = r * (+-ca), z1 = r * (+-sa) with the cosine negative in quadrants 1, 2
+// (bit 31 of b + 2^30) and the sine in quadrants 2, 3 (bit 31 of b); flipping the product's sign bit is the same as negating
+// a factor.
+__device__ __forceinline__ void bm_rotate(const uint32_t b, const float r, const float sn, const float cs, float& z0, float& z1) {
+    const bool odd = (b & 0x40000000u) != 0u;
+    const float ca = odd ? sn : cs, sa = odd ? cs : sn;
+    // x ^ (y & 0x80000000): truth table 0xf0 ^ (0xcc & 0xaa) = 0x78 (operands count 0xf0, 0xcc, 0xaa)
+    z0 = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(r * ca), b + 0x40000000u, 0x80000000u, 0x78));
+    z1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(r * sa), b, 0x80000000u, 0x78));
 }
 
 // -log2 polynomial, sin/cos polynomials: tools/fit_normal_polys.py
@@ -105,7 +136,7 @@ __device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& z0
     q = __builtin_fmaf(q, t, CCV_Q1);
     q = __builtin_fmaf(q, t, CCV_Q0);
     const float L = __builtin_fmaf(-t, q, L0);       // -log2(u1) >= 0
-    const float r = __builtin_sqrtf(L * 0x1.62e430p+0f);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+    const float r = sqrt_cr_radius(L * 0x1.62e430p+0f);   // correctly rounded
 
     const uint32_t quad = b >> 30;
     const int32_t f = (int32_t)(b & 0x3FFFFFFFu) - (1 << 29);
@@ -121,12 +152,8 @@ __device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& z0
     const float sn = __builtin_fmaf(al * w, s, al);
     const float cs = __builtin_fmaf(w, c, 1.0f);
     // rotate by quadrant: (cos,sin)(theta) for theta = quad*pi/2 + al
-    const float ca = (quad & 1u) ? sn : cs;
-    const float sa = (quad & 1u) ? cs : sn;
-    const float cq = (quad == 1u || quad == 2u) ? -ca : ca;
-    const float sq = (quad >= 2u) ? -sa : sa;
-    z0 = r * cq;
-    z1 = r * sq;
+    (void)quad;
+    bm_rotate(b, r, sn, cs, z0, z1);
 }
 
 // N independent Box-Muller pairs, stage by stage (the same per-element arithmetic as box_muller_f32, bit for bit): the
@@ -134,7 +161,6 @@ __device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& z0
 template <int N>
 __device__ __forceinline__ void box_muller_f32_n(const uint32_t (&a)[N], const uint32_t (&b)[N], float (&z0)[N], float (&z1)[N]) {
     float t[N], L0[N], q[N], al[N], w[N], s[N], c[N], r[N];
-    uint32_t quad[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const uint32_t a1 = a[i] == 0u ? 1u : a[i];
@@ -143,7 +169,6 @@ __device__ __forceinline__ void box_muller_f32_n(const uint32_t (&a)[N], const u
         const bool fold = m > 0xB504F333u;
         t[i] = fold ? -((float)(0u - m) * 0x1p-32f) : (float)(m - 0x80000000u) * 0x1p-31f;
         L0[i] = (float)(1 + lz - (fold ? 1 : 0));
-        quad[i] = b[i] >> 30;
         const int32_t f = (int32_t)(b[i] & 0x3FFFFFFFu) - (1 << 29);
         al[i] = (float)f * 0x1.921fb6p-30f;
         w[i] = al[i] * al[i];
@@ -173,19 +198,14 @@ __device__ __forceinline__ void box_muller_f32_n(const uint32_t (&a)[N], const u
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const float L = __builtin_fmaf(-t[i], q[i], L0[i]);
-        r[i] = __builtin_sqrtf(L * 0x1.62e430p+0f);
+        r[i] = sqrt_cr_radius(L * 0x1.62e430p+0f);
     }
     CCV_KEEP_ORDER();
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const float sn = __builtin_fmaf(al[i] * w[i], s[i], al[i]);
         const float cs = __builtin_fmaf(w[i], c[i], 1.0f);
-        const float ca = (quad[i] & 1u) ? sn : cs;
-        const float sa = (quad[i] & 1u) ? cs : sn;
-        const float cq = (quad[i] == 1u || quad[i] == 2u) ? -ca : ca;
-        const float sq = (quad[i] >= 2u) ? -sa : sa;
-        z0[i] = r[i] * cq;
-        z1[i] = r[i] * sq;
+        bm_rotate(b[i], r[i], sn, cs, z0[i], z1[i]);
     }
 }
 
