@@ -84,6 +84,25 @@ struct R4Shared {
     int seq[8];
 };
 
+// The per-lane sample indices, made afresh where a role (or the epilogue) needs them: five values that are live from the
+// first instruction to the last would otherwise be spilled at 128 registers (the asm statement keeps the compiler from
+// merging the copies back into one).
+struct R4Lane {
+    int lane, k, kk;
+    bool live;
+    uint32_t kg;
+};
+__device__ __forceinline__ R4Lane r4_lane(const RolloutArgs& A) {
+    R4Lane L;
+    L.lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (all 64 lanes are active here)
+    asm volatile("" : "+v"(L.lane));
+    L.k = (int)blockIdx.x * kPcSamples + L.lane;
+    L.live = L.k < A.K;
+    L.kk = L.live ? L.k : A.K - 1;
+    L.kg = (uint32_t)(A.k_offset + L.kk);
+    return L;
+}
+
 template <int MODEL, int MODE>
 __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutArgs Ak, const Window Wk) {
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
@@ -94,15 +113,11 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     static_assert(offsetof(R4Shared<MODEL>, zs) + sizeof(sh.zs) >= kR4Waves * kR4RB * (kPcSamples + 1) * sizeof(double), "epilogue buffers");
     const RolloutArgs A = with_resident_pose(Ak);
     const int H = A.H;
-    const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if constexpr (COST) stage_window(A, Wk, sh, kR4Waves * 64);
     if constexpr (MODE == MODE_FUSED) pc_stage_nominal<MODEL>(A, sh, kR4Waves * 64);
-    const int k = blockIdx.x * kPcSamples + lane;
-    const bool live = k < A.K;
-    const int kk = live ? k : A.K - 1;
-    const uint32_t kg = (uint32_t)(A.k_offset + kk);
-    double cost = 0.0;
+    // (every role keeps its own cost part and drops it into LDS at the end of its loop: one variable across the four
+    //  branches and the epilogue gets spilled)
     const int nblocks = (H + kTU - 1) / kTU;
     const int nstates = H;   // states that reach the path cost (dd:199)
     // blocks whose 8 steps all carry controls: their normals come from the noise wave (the last, partial block is the
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         if constexpr (MODE == MODE_FUSED) {   // (stage-wise cost call: fp64 controls, 120 registers -- fetched after the barrier)
             if (rows.n > 0) {
                 pc_wait_for(seq_stored, nb_early);   // the rows are in HBM / L2
-                r4_fetch0(A, upd, rows, kk);
+                r4_fetch0(A, upd, rows, r4_lane(A).kk);
             }
         }
     };
@@ -132,6 +147,9 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         // ---------------- noise wave
         if constexpr (MODE == MODE_FUSED) {
             constexpr int NCALL = kTU * UD / 4;
+            const R4Lane L = r4_lane(A);
+            const int lane = L.lane;
+            const uint32_t kg = L.kg;
             for (int b = 0; b < nfull; ++b) {
                 pc_rotate_priority(A, b);
                 if (b >= 2) {   // zs[b & 1] last held block b-2: the dynamics wave is through it, the store wave has loaded it
@@ -157,10 +175,16 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                 pc_publish(seq_noise, b + 1);
             }
         }
+        if constexpr (COST) sh.cost[0][r4_lane(A).lane] = 0.0;
         if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
         early_fetch();
     } else if (wv == 1) {
         // ---------------- dynamics wave: all time blocks, state in registers
+        const R4Lane L = r4_lane(A);
+        const int lane = L.lane, k = L.k, kk = L.kk;
+        const bool live = L.live;
+        const uint32_t kg = L.kg;
+        double cost = 0.0;
         PcState<MODEL> S;
         S.x = A.x0[0];
         S.y = A.x0[1];
@@ -200,11 +224,14 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
             }
             pc_publish(seq_ready, b + 1);
         }
+        if constexpr (COST) sh.cost[1][lane] = cost;
         if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
         early_fetch();
     } else if (wv == 2) {
         // ---------------- distance wave: the states of block b as soon as the dynamics wave has published it
         int prune_on = 1;
+        const int lane = r4_lane(A).lane;
+        double cost = 0.0;
         for (int b = 0; b < nblocks; ++b) {
             pc_rotate_priority(A, b + 2);
             pc_wait_for(seq_ready, b + 1);
@@ -228,10 +255,13 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
 #endif
             if (!taken) pc_publish(seq_dist, b + 1);   // (nothing of this block reaches the path cost)
         }
+        if constexpr (COST) sh.cost[2][lane] = cost;
     } else {
         // ---------------- store wave: normals (MODE_FUSED) and states (not in MODE_COST) of block b, LDS -> registers ->
         // HBM.  Everything is read from LDS first and the buffer handed back before the first store issues.
         const size_t pitch = (size_t)A.pitch;
+        const R4Lane L = r4_lane(A);
+        const int lane = L.lane, k = L.k;
         for (int b = 0; b < nblocks; ++b) {
             pc_rotate_priority(A, b + 3);
             pc_wait_for(seq_ready, b + 1);
@@ -287,12 +317,15 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         // the other waves re-read the rows of normals in the epilogue: all of this wave's stores are acknowledged before the
         // barrier below
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (COST) sh.cost[3][lane] = 0.0;
     }
     if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
     if constexpr (COST) {
         const int R = (H - 1) * UD;
         const int mcount = rows.n;
-        sh.cost[wv][lane] = cost;
+        const R4Lane L = r4_lane(A);
+        const int lane = L.lane, k = L.k, kk = L.kk;
+        const bool live = L.live;
         // the one barrier of the kernel: every wave is through its loop (the store wave with all its stores acknowledged),
         // the cost parts are in LDS, and p / ab / c / zs are dead
         pc_barrier_lds();
