@@ -43,7 +43,7 @@ def _free_port():
 @pytest.mark.parametrize("forced", [None, "solo"])
 def test_c5_eight_shards_equal_one_handle(monkeypatch, forced):
     """C5 as the 8-GPU run shards it (sample_offset = g * 65 536, C2 parameters) against ONE handle with K = 524 288.
-    Default kernels: the shards run the three-wave kernel, the whole runs the one-wave kernel -- same samples and states,
+    Default kernels: the shards run the four-wave kernel, the whole runs the one-wave kernel -- same samples and states,
     costs equal up to the order of a sample's cost terms.  With the one-wave kernel forced for the shards as well, every
     per-sample cost is the same bits.  Either way the sum of the eight partial vectors gives the whole's u*."""
     import torch

@@ -180,7 +180,7 @@ def test_fused_equals_stagewise_bitwise(name):
 
 @pytest.mark.parametrize("name", ["dd_K256_H50_sinusoid_C2", "sd_K256_H50_sinusoid_C3", "fb_K128_H80_dkan_C4"])
 def test_kernel_variants_agree(monkeypatch, name):
-    """The production kernels (two or three waves share 64 samples) against the plain one-sample-per-lane variants kept for
+    """The production kernels (two or four waves share 64 samples) against the plain one-sample-per-lane variants kept for
     experiments (CCV_MPPI_KERNEL=v1, LDS or scalar-load window): same samples, costs equal up to summation order."""
     p, kind = CASES[name]
     path = helpers.oracle_path(kind)
@@ -246,7 +246,7 @@ def test_multi_wave_kernels_agree(monkeypatch, wl, K, H):
                                     ("C2", 1000, 50), ("C3", 321, 50)])
 def test_one_wave_kernel_agrees_with_the_multi_wave_kernels(monkeypatch, wl, K, H):
     """Full body with two or more blocks of 64 samples per SIMD runs k_rollout_solo (one wave per 64 samples, no barrier
-    in the time loop, mppi_rollout_solo.h).  Same building blocks as the two- / three-wave kernels: same samples and
+    in the time loop, mppi_rollout_solo.h).  Same building blocks as the multi-wave kernels: same samples and
     states bit for bit, costs and controls equal up to the order in which the cost terms are added; and equal to the
     oracle within the north_star tolerance."""
     w = configs.workload(wl)

@@ -2,10 +2,4 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/r4n
-timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r4n/pytest.txt 2>&1; rc=$?
-tail -3 gpurun_out/r4n/pytest.txt
-[ $rc -eq 0 ] || exit 1
-export BENCH_ARGS="--steps 400 --warmup 20 --no-cpu-baseline --no-closed-loop-leg"
-timeout -k 10 300 bash tools/ab_bench.sh r4n 3 -- "new=X=1"
-BENCH_ARGS="--workload C3 --steps 200 --warmup 20 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r4n_c3 2 -- "new=X=1"
+timeout -k 10 1100 bash tools/profile_r02.sh r02t
