@@ -52,17 +52,29 @@ __device__ __forceinline__ R4Rows r4_rows(const int H, const int nblocks, const 
         default: return R4Rows{r_early + half_l, R - r_early - half_l};
     }
 }
+// Stores with a scalar base: address = (uniform 64-bit row pointer) + (32-bit lane offset).  The compiler hoists the
+// zero-extension of the lane offset out of the loop and then adds 64-bit vector addresses (one v_lshl_add_u64 per store,
+// 198 per workgroup); written out, a store issues no vector instruction for its address.  The store wave counts its own
+// vector-memory operations (s_waitcnt vmcnt below), so nothing depends on the compiler seeing these.
+__device__ __forceinline__ void r4_store_f32(char* const row, const uint32_t lane_off, const float v) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
+}
+__device__ __forceinline__ void r4_store_f64_stream(char* const row, const uint32_t lane_off, const double v) {   // (non-temporal)
+    asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
+}
+
 // first chunk of a range: row i of the chunk is i rows past the range's first one (one scalar add per address)
 template <class T>
 __device__ __forceinline__ void r4_fetch0(const RolloutArgs& A, T (&v)[kUpdCH], const R4Rows& rows, const int kk) {
     const size_t pitch = (size_t)A.pitch;
-    const T* p0;
-    if constexpr (std::is_same<T, float>::value) p0 = A.z + kk + (size_t)rows.first * pitch;   // fused: the normals
-    else p0 = A.u + kk + (size_t)rows.first * pitch;
+    const char* p0;   // (uniform row pointer + 32-bit lane offset: scalar-base loads)
+    if constexpr (std::is_same<T, float>::value) p0 = reinterpret_cast<const char*>(A.z + (size_t)rows.first * pitch);   // fused: the normals
+    else p0 = reinterpret_cast<const char*>(A.u + (size_t)rows.first * pitch);
+    const uint32_t koff = (uint32_t)kk * (uint32_t)sizeof(T);
 #pragma unroll
     for (int i = 0; i < kUpdCH; ++i) {
         v[i] = 0;
-        if (i < rows.n) v[i] = p0[(size_t)i * pitch];
+        if (i < rows.n) v[i] = *reinterpret_cast<const T*>(p0 + (size_t)i * (pitch * sizeof(T)) + koff);
     }
 }
 
@@ -261,7 +273,8 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         // HBM.  Everything is read from LDS first and the buffer handed back before the first store issues.
         const size_t pitch = (size_t)A.pitch;
         const R4Lane L = r4_lane(A);
-        const int lane = L.lane, k = L.k;
+        const int lane = L.lane;
+        const uint32_t koff4 = (uint32_t)L.k * 4u, koff8 = (uint32_t)L.k * 8u;
         for (int b = 0; b < nblocks; ++b) {
             pc_rotate_priority(A, b + 3);
             pc_wait_for(seq_ready, b + 1);
@@ -282,22 +295,26 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             pc_publish(seq_store, b + 1);
 #if !defined(CCV_ABL_NO_STORE)
+            // (the row pitch in bytes stays below 4 GB by construction: 32-bit lane offsets)
             if constexpr (MODE == MODE_FUSED) {
                 const int nrows = min(kTU, H - 1 - t0) * UD;   // control steps t < H-1
+                char* const zrow = reinterpret_cast<char*>(A.z + (size_t)(t0 * UD) * pitch);
                 static_for<kTU * UD>([&](auto RR) {
                     constexpr int r = decltype(RR)::value;
                     // rows are padded to a multiple of 64 samples (pitch): lanes past K write their padding slot
-                    if (r < nrows) A.z[(size_t)(t0 * UD + r) * pitch + k] = zv[r];
+                    if (r < nrows) r4_store_f32(zrow + (size_t)r * (pitch * 4), koff4, zv[r]);
                 });
             }
             if constexpr (MODE != MODE_COST) {
                 if (A.store_xy) {
                     const int nst = min(kTU, H - t0);           // states t < H
+                    char* const xrow = reinterpret_cast<char*>(A.xs + (size_t)t0 * pitch);
+                    char* const yrow = reinterpret_cast<char*>(A.ys + (size_t)t0 * pitch);
 #pragma unroll
                     for (int tt = 0; tt < kTU; ++tt) {
                         if (tt < nst) {
-                            CCV_STATE_STORE(&A.xs[(size_t)(t0 + tt) * pitch + k], xv[tt]);
-                            CCV_STATE_STORE(&A.ys[(size_t)(t0 + tt) * pitch + k], yv[tt]);
+                            r4_store_f64_stream(xrow + (size_t)tt * (pitch * 8), koff8, xv[tt]);
+                            r4_store_f64_stream(yrow + (size_t)tt * (pitch * 8), koff8, yv[tt]);
                         }
                     }
                 }
