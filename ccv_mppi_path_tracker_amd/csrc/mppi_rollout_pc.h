@@ -131,6 +131,21 @@ __device__ __forceinline__ double pc_control_from_normal(const RolloutArgs& A, c
 #define CCV_STATE_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #endif
 
+// Stores with a scalar base: address = (uniform 64-bit row pointer) + (32-bit lane offset).  The compiler hoists the
+// zero-extension of the lane offset out of the loop and then adds 64-bit vector addresses (one v_lshl_add_u64 per store,
+// 198 per workgroup at C2); written out, a store issues no vector instruction for its address.  The compiler does not count
+// these among the outstanding vector-memory operations: its own s_waitcnt vmcnt(n) then waits for more than it needs to, never
+// for less (the counter covers them and operations complete in order), and the four-wave kernel's store wave counts its own.
+// The row pitch in bytes stays below 4 GB by construction (32-bit lane offsets).  Used by the four-wave kernel's store wave
+// (C2 -0.3 us, C3 -1.2 us); in the one-wave kernels the row pointers cost scalar registers they do not have (full body:
+// 97 spilled SGPRs, 229.7 -> 232.0 us), so those keep the compiler's addressing.
+__device__ __forceinline__ void pc_store_f32(char* const row, const uint32_t lane_off, const float v) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
+}
+__device__ __forceinline__ void pc_store_f64_stream(char* const row, const uint32_t lane_off, const double v) {   // (non-temporal)
+    asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
+}
+
 // Wave arbitration on a SIMD is by priority, then age: with every workgroup at priority 0 the workgroup dispatched first
 // to a CU runs almost unimpeded and the last one gets the left-over issue slots -- measured at K = 65 536, four
 // workgroups per CU: 26 / 33 / 41 / 45 us for the same work, and the kernel ends with the slowest.  Alternating which

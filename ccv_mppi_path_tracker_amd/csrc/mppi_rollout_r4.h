@@ -52,17 +52,6 @@ __device__ __forceinline__ R4Rows r4_rows(const int H, const int nblocks, const 
         default: return R4Rows{r_early + half_l, R - r_early - half_l};
     }
 }
-// Stores with a scalar base: address = (uniform 64-bit row pointer) + (32-bit lane offset).  The compiler hoists the
-// zero-extension of the lane offset out of the loop and then adds 64-bit vector addresses (one v_lshl_add_u64 per store,
-// 198 per workgroup); written out, a store issues no vector instruction for its address.  The store wave counts its own
-// vector-memory operations (s_waitcnt vmcnt below), so nothing depends on the compiler seeing these.
-__device__ __forceinline__ void r4_store_f32(char* const row, const uint32_t lane_off, const float v) {
-    asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
-}
-__device__ __forceinline__ void r4_store_f64_stream(char* const row, const uint32_t lane_off, const double v) {   // (non-temporal)
-    asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
-}
-
 // first chunk of a range: row i of the chunk is i rows past the range's first one (one scalar add per address)
 template <class T>
 __device__ __forceinline__ void r4_fetch0(const RolloutArgs& A, T (&v)[kUpdCH], const R4Rows& rows, const int kk) {
@@ -302,7 +291,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                 static_for<kTU * UD>([&](auto RR) {
                     constexpr int r = decltype(RR)::value;
                     // rows are padded to a multiple of 64 samples (pitch): lanes past K write their padding slot
-                    if (r < nrows) r4_store_f32(zrow + (size_t)r * (pitch * 4), koff4, zv[r]);
+                    if (r < nrows) pc_store_f32(zrow + (size_t)r * (pitch * 4), koff4, zv[r]);
                 });
             }
             if constexpr (MODE != MODE_COST) {
@@ -313,8 +302,8 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
 #pragma unroll
                     for (int tt = 0; tt < kTU; ++tt) {
                         if (tt < nst) {
-                            r4_store_f64_stream(xrow + (size_t)tt * (pitch * 8), koff8, xv[tt]);
-                            r4_store_f64_stream(yrow + (size_t)tt * (pitch * 8), koff8, yv[tt]);
+                            pc_store_f64_stream(xrow + (size_t)tt * (pitch * 8), koff8, xv[tt]);
+                            pc_store_f64_stream(yrow + (size_t)tt * (pitch * 8), koff8, yv[tt]);
                         }
                     }
                 }

@@ -2,8 +2,9 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/r4r
-timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r4r/pytest.txt 2>&1; rc=$?
-tail -3 gpurun_out/r4r/pytest.txt
+mkdir -p gpurun_out/r4s
+timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_c5.py -x -q -m gpu > gpurun_out/r4s/pytest.txt 2>&1; rc=$?
+tail -3 gpurun_out/r4s/pytest.txt
 [ $rc -eq 0 ] || exit 1
-timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r4r/smoke.txt 2>&1; tail -5 gpurun_out/r4r/smoke.txt
+BENCH_ARGS="--workload C4 --steps 100 --warmup 10 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r4s_c4 3 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
+BENCH_ARGS="--samples-per-gpu 524288 --steps 60 --warmup 10 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r4s_k512 2 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
