@@ -164,6 +164,12 @@ void fill_args(const ccv_mppi_handle* h, RolloutArgs& A, const double* x0, doubl
         A.umin[d] = c.u_min[d];
         A.umax[d] = c.u_max[d];
     }
+    // two-instruction clamps (clampd_fast, mppi_kernels.h) give the reference's values when no control is NaN and no pair of
+    // bounds is out of order; the kernel adds its own test of the warm start
+    A.fast_clamp = std::isfinite(c.control_noise) ? 1 : 0;
+    for (int d = 0; d < udim_of(c.model); ++d)
+        if (!(c.u_min[d] <= c.u_max[d])) A.fast_clamp = 0;
+    if (std::getenv("CCV_MPPI_FAST_CLAMP") && std::atoi(std::getenv("CCV_MPPI_FAST_CLAMP")) == 0) A.fast_clamp = 0;   // (experiments)
     const bool roll_off = (c.flags & CCV_MPPI_FLAG_ROLL_OFF) != 0;
     A.w_path = c.path_weight;
     A.w_v = c.v_weight;

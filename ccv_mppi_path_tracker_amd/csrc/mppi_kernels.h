@@ -84,7 +84,7 @@ struct RolloutArgs {
     double* statpart;   // [nparts][3]: min cost, max cost, zero-weight count
     int32_t nparts, fuse_update;
     int32_t prio_rotate, cu_count;   // k_rollout_pc / k_rollout_r3: see pc_rotate_priority()
-    int32_t prune, reserved0;        // exact pruning of the window in the distance loop (pc_prune_window); 0 = off
+    int32_t prune, fast_clamp;       // exact pruning of the window in the distance loop (pc_prune_window); 0 = off.  fast_clamp: clampd_fast() allowed (host side: sigma finite, umin <= umax)
     // deferred ccv_mppi_apply_partials_enqueue (K sharded over devices): when set, the warm start is pending_vec[1..] /
     // pending_vec[0]; every workgroup forms it while staging u* in LDS and workgroup 0 writes it (and sum w) back
     const double* pending_vec;
@@ -147,6 +147,17 @@ __device__ __forceinline__ double div_uniform(const double x, const double d, co
 
 // dd:62-67
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// The same value in two instructions instead of six (two compares, four selects) -- for every v that is not NaN and bounds
+// with lo <= hi (NaN bounds pass v through in both forms).  The reference's clamp passes a NaN control through (dd:98-99: both
+// comparisons are false), min / max would replace it by a bound: the kernels use this form only where the host has checked
+// sigma and the bounds and the kernel itself has found no NaN in the warm start (RolloutArgs::fast_clamp; a control is
+// double(z) * sigma + u* with a finite z).  (-0 against a bound of +0 comes out as +0 here and -0 there: equal values.)
+__device__ __forceinline__ double clampd_fast(double v, double lo, double hi) { return __builtin_fmin(__builtin_fmax(v, lo), hi); }
+template <bool FAST>
+__device__ __forceinline__ double clampd_as(double v, double lo, double hi) {
+    if constexpr (FAST) return clampd_fast(v, lo, hi);
+    else return clampd(v, lo, hi);
+}
 
 // min over the H window points of (a_j*px + b_j*py + c_j) for NV trajectory points held in registers.
 // 2 FMA + 1 MIN per (point, window point): the O(K*H^2) core (calc_MinDistance, dd:183-192).

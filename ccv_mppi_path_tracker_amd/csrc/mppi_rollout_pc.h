@@ -84,9 +84,11 @@ struct PcShared {
 
 // The warm start u* is staged in LDS once per workgroup.  Read straight from memory inside the time loop (scalar or
 // vector loads) every block of 8 steps exposes one cache-miss latency -- ~1500 cycles, measured -- on the producer chain.
+// Returns whether one of the values this thread staged is NaN (see clampd_fast).
 template <int MODEL, class SH>
-__device__ __forceinline__ void pc_stage_nominal(const RolloutArgs& A, SH& sh, const int nthreads) {
+__device__ __forceinline__ bool pc_stage_nominal(const RolloutArgs& A, SH& sh, const int nthreads) {
     const int R = (A.H - 1) * udim_of(MODEL);
+    bool bad = false;
     if (A.pending_vec) {
         // K sharded over devices: the all-reduced [sum w, sum w*u] has not been divided yet -- do it here (the division
         // k_apply_partials would do, bit for bit) instead of spending a kernel launch on 100 quotients
@@ -94,28 +96,31 @@ __device__ __forceinline__ void pc_stage_nominal(const RolloutArgs& A, SH& sh, c
         for (int j = threadIdx.x; j < R + 8; j += nthreads) {
             const double v = j < R ? A.pending_vec[1 + j] / S : 0.0;
             sh.nom[j] = v;
+            bad |= v != v;
             if (blockIdx.x == 0 && j < R) {
                 A.nominal_w[j] = v;
                 A.nominal_used[j] = v;
             }
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) A.stats_w[0] = S;
-        return;
+        return bad;
     }
     for (int j = threadIdx.x; j < R + 8; j += nthreads) {
         const double v = j < R ? A.nominal[j] : 0.0;
         sh.nom[j] = v;
+        bad |= v != v;
         if (blockIdx.x == 0 && j < R) A.nominal_used[j] = v;   // (the normals are stored, not the controls: kept with them)
     }
+    return bad;
 }
 
 // The control of row n = t * u_dim + d from its normal: the samplers' arithmetic (double(z) * sigma + mean, clamp, steer_off),
 // so the same bits as the value the rollout used.  D = n % u_dim is a template argument: the clamp bounds then are scalar
 // kernel arguments (a run-time dimension would cost an integer division and two LDS reads with their waits per value).
-template <int MODEL, int D, class SH>
+template <int MODEL, int D, bool FASTCLAMP = false, class SH>
 __device__ __forceinline__ double pc_control_from_normal(const RolloutArgs& A, const SH& sh, const float z, const int n) {
     double v = (double)z * A.sigma + sh.nom[n];
-    v = clampd(v, arg5<D>(A.umin), arg5<D>(A.umax));
+    v = clampd_as<FASTCLAMP>(v, arg5<D>(A.umin), arg5<D>(A.umax));
     if constexpr (MODEL == CCV_MPPI_FULL_BODY && D == 2) {
         if (A.steer_off) v = 0.0;   // fb:517
     }
@@ -383,7 +388,7 @@ __device__ __forceinline__ void pc_noise_ahead(const RolloutArgs& A, float (*slo
 // interleave -- a lone wave then issues back to back instead of waiting out each chain's latency.
 // ---------------------------------------------------------------------------------------------------------------
 // ZLDS (four-wave kernel): the block's normals are already in sh.zs, made by the noise wave.
-template <int MODEL, int MODE, class SH, bool ZLDS = false>
+template <int MODEL, int MODE, class SH, bool ZLDS = false, bool FASTCLAMP = false>
 __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh, PcState<MODEL>& S, double& cost,
                                                    const int b, const int lane, const int k, const int kk, const bool live,
                                                    const uint32_t kg
@@ -427,7 +432,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
                 constexpr int tt = nloc / UD, d = nloc % UD;
                 // libstdc++ normal_distribution: ret * stddev + mean (dd:96-97), then clamp (dd:98-99)
                 double v = (double)z[i] * A.sigma + nomv[i];
-                v = clampd(v, arg5<d>(A.umin), arg5<d>(A.umax));
+                v = clampd_as<FASTCLAMP>(v, arg5<d>(A.umin), arg5<d>(A.umax));
                 if constexpr (FB && d == 2) {
                     if (A.steer_off) v = 0.0;   // fb:517
                 }
@@ -939,7 +944,8 @@ __device__ __forceinline__ void pc_update_fetch(const RolloutArgs& A, T (&v)[kUp
 // chunk into v.)
 template <int RB, int MODEL, class SH, class T, class ROWS>
 __device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, const SH& sh, double* buf, T (&v)[kUpdCH], const ROWS& rows,
-                                               const int mcount, const double wgt, const int lane, const int kk) {
+                                               const int mcount, const double wgt, const int lane, const int kk,
+                                               const bool fast_clamp = false) {   // (wave-uniform: see clampd_fast)
     static_assert(RB <= 16 && kUpdCH % RB == 0, "batch size");
     constexpr int STRIDE = kPcSamples + 1;   // padded row: lanes (r, q) hit different banks
     const int rr = lane >> 2, q = lane & 3;
@@ -950,20 +956,25 @@ __device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, const SH& s
             const int base = chunk0 + bb * RB;
             const int nrows = min(RB, mcount - base);
             if (nrows > 0) {
-                static_for<RB>([&](auto RR) {
-                    constexpr int r = decltype(RR)::value;
-                    if constexpr (std::is_same<T, float>::value) {
-                        // the row's control dimension: rows are dealt in units of ROWS::BR (a multiple of u_dim) and chunks of
-                        // kUpdCH (= 60: a multiple of 2, 3 and 5), so it only depends on the position inside the chunk
-                        constexpr int UD = udim_of(MODEL);
-                        static_assert(ROWS::BR % UD == 0 && kUpdCH % UD == 0, "row dealing vs control dimension");
-                        constexpr int d = (bb * RB + r) % UD;
-                        const int row = rows.row(min(base + r, mcount - 1));   // (rows past the end: clamped, never summed)
-                        buf[r * STRIDE + lane] = wgt * pc_control_from_normal<MODEL, d>(A, sh, v[bb * RB + r], row);
-                    } else {
-                        buf[r * STRIDE + lane] = wgt * v[bb * RB + r];
-                    }
-                });
+                auto products = [&](auto FAST_) {
+                    constexpr bool FAST = decltype(FAST_)::value;
+                    static_for<RB>([&](auto RR) {
+                        constexpr int r = decltype(RR)::value;
+                        if constexpr (std::is_same<T, float>::value) {
+                            // the row's control dimension: rows are dealt in units of ROWS::BR (a multiple of u_dim) and chunks
+                            // of kUpdCH (= 60: a multiple of 2, 3 and 5), so it only depends on the position inside the chunk
+                            constexpr int UD = udim_of(MODEL);
+                            static_assert(ROWS::BR % UD == 0 && kUpdCH % UD == 0, "row dealing vs control dimension");
+                            constexpr int d = (bb * RB + r) % UD;
+                            const int row = rows.row(min(base + r, mcount - 1));   // (rows past the end: clamped, never summed)
+                            buf[r * STRIDE + lane] = wgt * pc_control_from_normal<MODEL, d, FAST>(A, sh, v[bb * RB + r], row);
+                        } else {
+                            buf[r * STRIDE + lane] = wgt * v[bb * RB + r];
+                        }
+                    });
+                };
+                if (std::is_same<T, float>::value && fast_clamp) products(std::true_type{});
+                else products(std::false_type{});
                 __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed (wave-private buffer)
                 __builtin_amdgcn_wave_barrier();
                 double acc = 0.0;

@@ -115,8 +115,12 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     const RolloutArgs A = with_resident_pose(Ak);
     const int H = A.H;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < 8) sh.seq[threadIdx.x] = 0;
+    __syncthreads();   // (the sequence numbers are zero before seq[5], the "NaN in the warm start" flag, can be raised)
     if constexpr (COST) stage_window(A, Wk, sh, kR4Waves * 64);
-    if constexpr (MODE == MODE_FUSED) pc_stage_nominal<MODEL>(A, sh, kR4Waves * 64);
+    if constexpr (MODE == MODE_FUSED) {
+        if (pc_stage_nominal<MODEL>(A, sh, kR4Waves * 64)) sh.seq[5] = 1;
+    }
     // (every role keeps its own cost part and drops it into LDS at the end of its loop: one variable across the four
     //  branches and the epilogue gets spilled)
     const int nblocks = (H + kTU - 1) / kTU;
@@ -124,8 +128,9 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     // blocks whose 8 steps all carry controls: their normals come from the noise wave (the last, partial block is the
     // dynamics wave's own: pc_produce)
     const int nfull = MODE == MODE_FUSED ? (H - 1) / kTU : 0;
-    if (threadIdx.x < 8) sh.seq[threadIdx.x] = 0;
     __syncthreads();
+    // two-instruction clamps (clampd_fast): the host has checked sigma and the bounds, the staging found no NaN in u*
+    const bool fast_clamp = MODE == MODE_FUSED && A.fast_clamp && __builtin_amdgcn_readfirstlane(sh.seq[5]) == 0;
     int* const seq_noise = &sh.seq[0];
     int* const seq_ready = &sh.seq[1];
     int* const seq_dist = &sh.seq[2];
@@ -206,9 +211,9 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                 pc_wait_for(seq_dist, b - 1);
                 pc_wait_for(seq_store, b - 1);
             }
-            if (b < nfull) {
-                pc_wait_for(seq_noise, b + 1);
-                pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true>(A, sh, S, cost, b, lane, k, kk, live, kg
+            if (b < nfull) pc_wait_for(seq_noise, b + 1);
+            if (b < nfull && fast_clamp) {
+                pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true>(A, sh, S, cost, b, lane, k, kk, live, kg
 #if defined(CCV_STAMP)
                                                                      , ST
 #endif
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         }
         if (A.fuse_update) {
             double* buf = &sh.p[0][0][0][0] + wv * (kR4RB * (kPcSamples + 1));
-            pc_reduce_rows<kR4RB, MODEL>(A, sh, buf, upd, rows, mcount, wgt, lane, kk);
+            pc_reduce_rows<kR4RB, MODEL>(A, sh, buf, upd, rows, mcount, wgt, lane, kk, fast_clamp);
             if (wv == kR4Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
         }
     }

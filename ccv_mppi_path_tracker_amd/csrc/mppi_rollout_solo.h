@@ -35,7 +35,9 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
     const int H = A.H;
     const int lane = threadIdx.x;
     stage_window(A, Wk, sh, kPcSamples);
-    pc_stage_nominal<MODEL>(A, sh, kPcSamples);
+    // two-instruction clamps (clampd_fast, mppi_kernels.h): the host has checked sigma and the bounds, this wave the warm start;
+    // a NaN anywhere takes every block through pc_produce and its compare-and-select clamp
+    const bool fast_clamp = A.fast_clamp && __builtin_amdgcn_ballot_w64(pc_stage_nominal<MODEL>(A, sh, kPcSamples)) == 0ull;
     const int k = blockIdx.x * kPcSamples + lane;
     const bool live = k < A.K;
     const int kk = live ? k : A.K - 1;
@@ -63,11 +65,12 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
     for (int b = 0; b < nblocks; ++b) {
         // ---------------- states and controls of steps 8b .. 8b+7
         bool done = false;
-        if (b * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg
+        if (fast_clamp && b * kTU + kTU <= H - 1)
+            done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, true>(A, sh, S, cost, b, lane, k, kk, live, kg
 #if defined(CCV_STAMP)
-                                                                          , ST
+                                                                                  , ST
 #endif
-        );
+            );
         if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
         // ---------------- their distance to the window
         const int nv = min(kTU, nstates - b * kTU);
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
         A.w[k] = wgt;
     }
     if (A.fuse_update) {
-        pc_reduce_rows<kUpdRB, MODEL>(A, sh, &sh.p[0][0][0][0], upd, rows, mcount, wgt, lane, kk);
+        pc_reduce_rows<kUpdRB, MODEL>(A, sh, &sh.p[0][0][0][0], upd, rows, mcount, wgt, lane, kk, fast_clamp);
         pc_block_stats(A, R, wgt, total, live, lane);
     }
 }
