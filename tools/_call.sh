@@ -2,8 +2,8 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/r4x
-timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r4x/pytest.txt 2>&1; rc=$?
-tail -15 gpurun_out/r4x/pytest.txt
+mkdir -p gpurun_out/r4y
+timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r4y/pytest.txt 2>&1; rc=$?
+tail -5 gpurun_out/r4y/pytest.txt
 [ $rc -eq 0 ] || exit 1
-BENCH_ARGS="--workload C3 --steps 200 --warmup 20 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r4x_c3 3 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
+BENCH_ARGS="--workload C4 --steps 100 --warmup 10 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r4y_c4 3 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
