@@ -326,6 +326,62 @@ def test_all_weights_underflow_gives_nan_like_the_reference():
     np.testing.assert_allclose(u2, np.einsum("i,itd->td", w / w.sum(), u), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("wl,K,H", [("C2", 1000, 50), ("C3", 640, 50), ("C4", 512, 80), ("C2", 200, 9)])
+def test_two_instruction_clamp_equals_compare_and_select(monkeypatch, wl, K, H):
+    """The rollout kernels clamp with v_max / v_min where no control can be NaN (sigma finite, bounds in order -- checked on
+    the host -- and no NaN in the staged warm start -- checked by the kernel) and with the reference's compare-and-select
+    otherwise (dd:98-99 passes a NaN through).  CCV_MPPI_FAST_CLAMP=0 forces the second form: the controls must be the same
+    bits -- with bounds that really bite -- and everything downstream equal up to the sin / cos formulation of the block
+    path the forced run takes."""
+    w = configs.workload(wl)
+    p = w.params.with_(num_samples=K, horizon=H, control_noise=1.5)   # (wide noise: many samples at a bound)
+    path = helpers.oracle_path(w.path)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    monkeypatch.delenv("CCV_MPPI_FAST_CLAMP", raising=False)
+    a = MPPIController(p)
+    monkeypatch.setenv("CCV_MPPI_FAST_CLAMP", "0")
+    b = MPPIController(p)
+    ua = a.iterate(state, p.dt, xr, yr, yaw[0], 5, 0, want_stats=False)
+    ub = b.iterate(state, p.dt, xr, yr, yaw[0], 5, 0, want_stats=False)
+    ca, cb = a.read_controls(), b.read_controls()
+    np.testing.assert_array_equal(ca, cb)
+    lo, hi = np.array(p.u_min[:p.udim]), np.array(p.u_max[:p.udim])
+    assert np.mean((ca == lo) | (ca == hi)) > 0.05 and np.all(ca >= lo) and np.all(ca <= hi)
+    np.testing.assert_allclose(a.read_candidates(), b.read_candidates(), rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(a.read_costs(), b.read_costs(), rtol=1e-9)
+    np.testing.assert_allclose(ua, ub, rtol=1e-8, atol=1e-11)
+    o = helpers.oracle_for(p)
+    uo = o.iterate(state, p.dt, xr, yr, yaw[0], seed=5, rng="philox", iteration=0)
+    np.testing.assert_array_equal(ca, o.get_controls())
+    np.testing.assert_allclose(ua, uo, rtol=TOL_U, atol=1e-12)
+
+
+@pytest.mark.parametrize("wl,K,H", [("C2", 256, 50), ("C4", 256, 80)])
+def test_nan_in_the_warm_start_passes_through_the_clamp(wl, K, H):
+    """A NaN in u* (e.g. after an all-underflow update) makes every control of its row NaN in the reference -- the clamp's two
+    comparisons are false (dd:98-99).  The kernels must notice the NaN when they stage the warm start and must not clamp it to
+    a bound with v_max / v_min: the row's controls are NaN, the other rows' controls are the oracle's bits."""
+    w = configs.workload(wl)
+    p = w.params.with_(num_samples=K, horizon=H)
+    path = helpers.oracle_path(w.path)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    g, o = MPPIController(p), helpers.oracle_for(p)
+    nom = np.zeros((H - 1, p.udim))
+    nom[3, 1] = np.nan
+    g.set_nominal(nom)
+    o.set_nominal(nom)
+    g.iterate(state, p.dt, xr, yr, yaw[0], 9, 0, want_stats=False)
+    o.iterate(state, p.dt, xr, yr, yaw[0], seed=9, rng="philox", iteration=0)
+    cg, co = g.read_controls(), o.get_controls()
+    assert np.all(np.isnan(cg[:, 3, 1])) and np.all(np.isnan(co[:, 3, 1]))
+    keep = np.ones(cg.shape[1:], dtype=bool)
+    keep[3, 1] = False
+    np.testing.assert_array_equal(cg[:, keep], co[:, keep])
+    assert np.all(np.isfinite(cg[:, keep]))
+
+
 def test_distance_gate_100m():
     """calc_MinDistance starts from min_distance = 100 (dd:185): farther points all cost path_weight*100^2."""
     p = configs.diff_drive_defaults(64, 10)
