@@ -864,8 +864,25 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
                 asm("v_min_f64 %0, %1, %2" : "=v"(m[i]) : "v"(m[i]), "v"(t));
             }
         };
+        // the first pair of points starts the minimum (no +inf to initialise, no minimum against it: the hull is never empty,
+        // je - jb is a multiple of 4, and min(+inf, t) = t for every t the loop can produce but NaN, which ends at the gate
+        // value either way); the read-ahead ends inside the arrays' padding
+        auto first2 = [&](const double2(&ab)[2], const double(&c)[2]) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const double f0 = fma(ab[0].x, px[i], fma(ab[0].y, py[i], c[0]));
+                const double f1 = fma(ab[1].x, px[i], fma(ab[1].y, py[i], c[1]));
+                m[i] = fmin(f0, f1);
+            }
+        };
         fetch2(qa, ca, jb);
-        for (int j = jb; j < je; j += 4) {   // (je - jb is a multiple of 4; the read-ahead ends inside the arrays' padding)
+        fetch2(qb, cb, jb + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        first2(qa, ca);
+        fetch2(qa, ca, jb + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        points2(qb, cb);
+        for (int j = jb + 4; j < je; j += 4) {
             fetch2(qb, cb, j + 2);
             __builtin_amdgcn_sched_barrier(0);
             points2(qa, ca);

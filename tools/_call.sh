@@ -1,10 +1,10 @@
 #!/bin/bash
+set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/r4z
-for i in 1 2 3 4; do
-  for v in 1 0; do
-    CCV_BENCH_SPIN=$v timeout -k 10 120 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-closed-loop-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('spin=$v  %.2f us/step  kernel %.2f' % (1e3*d['ms_per_step'], d['roofline']['kernel_avg_us']))"
-  done
-done | tee gpurun_out/r4z/spin.txt
-timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "clamp or nan" > gpurun_out/r4z/pytest.txt 2>&1; tail -5 gpurun_out/r4z/pytest.txt
+mkdir -p gpurun_out/r5a
+timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/r5a/pytest.txt 2>&1; rc=$?
+tail -4 gpurun_out/r5a/pytest.txt
+[ $rc -eq 0 ] || exit 1
+BENCH_ARGS="--steps 400 --warmup 20 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5a 3 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
+BENCH_ARGS="--workload C3 --steps 200 --warmup 20 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5a_c3 2 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
