@@ -1,10 +1,9 @@
 #!/bin/bash
-set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/r5b
-timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_c5.py -x -q -m gpu > gpurun_out/r5b/pytest.txt 2>&1; rc=$?
-tail -4 gpurun_out/r5b/pytest.txt
-[ $rc -eq 0 ] || exit 1
-BENCH_ARGS="--workload C4 --steps 100 --warmup 10 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5b_c4 3 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
-BENCH_ARGS="--samples-per-gpu 524288 --steps 60 --warmup 10 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5b_k512 2 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
+mkdir -p gpurun_out/r5c
+for i in 1 2 3 4 5; do
+  for v in 1 0; do
+    CCV_BENCH_POLL=$v timeout -k 10 120 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-closed-loop-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('poll=$v  %.2f us/step  kernel %.2f' % (1e3*d['ms_per_step'], d['roofline']['kernel_avg_us']))"
+  done
+done | tee gpurun_out/r5c/poll.txt
