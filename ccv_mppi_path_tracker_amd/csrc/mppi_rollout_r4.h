@@ -211,13 +211,21 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                 pc_wait_for(seq_dist, b - 1);
                 pc_wait_for(seq_store, b - 1);
             }
-            if (b < nfull) pc_wait_for(seq_noise, b + 1);
-            if (b < nfull && fast_clamp) {
-                pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true>(A, sh, S, cost, b, lane, k, kk, live, kg
+            if (b < nfull) {
+                pc_wait_for(seq_noise, b + 1);
+                // (two instantiations: a NaN in the warm start is rare, but its results are to be the other kernels' bits too)
+                if (fast_clamp)
+                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true>(A, sh, S, cost, b, lane, k, kk, live, kg
 #if defined(CCV_STAMP)
-                                                                     , ST
+                                                                         , ST
 #endif
-                );
+                    );
+                else
+                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, false>(A, sh, S, cost, b, lane, k, kk, live, kg
+#if defined(CCV_STAMP)
+                                                                          , ST
+#endif
+                    );
             } else {
                 bool done = false;
                 if (MODE != MODE_FUSED && b * kTU + kTU <= H - 1)

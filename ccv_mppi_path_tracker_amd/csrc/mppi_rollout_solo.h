@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
     const int lane = threadIdx.x;
     stage_window(A, Wk, sh, kPcSamples);
     // two-instruction clamps (clampd_fast, mppi_kernels.h): the host has checked sigma and the bounds, this wave the warm start;
-    // a NaN anywhere takes every block through pc_produce and its compare-and-select clamp
+    // a NaN anywhere takes every block through the compare-and-select instantiation
     const bool fast_clamp = A.fast_clamp && __builtin_amdgcn_ballot_w64(pc_stage_nominal<MODEL>(A, sh, kPcSamples)) == 0ull;
     const int k = blockIdx.x * kPcSamples + lane;
     const bool live = k < A.K;
@@ -65,12 +65,22 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
     for (int b = 0; b < nblocks; ++b) {
         // ---------------- states and controls of steps 8b .. 8b+7
         bool done = false;
-        if (fast_clamp && b * kTU + kTU <= H - 1)
-            done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, true>(A, sh, S, cost, b, lane, k, kk, live, kg
+        if (b * kTU + kTU <= H - 1) {
+            if (fast_clamp)
+                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, true>(A, sh, S, cost, b, lane, k, kk, live, kg
 #if defined(CCV_STAMP)
-                                                                                  , ST
+                                                                                      , ST
 #endif
-            );
+                );
+            else if constexpr (!FB)   // (a second instantiation, so that a NaN in the warm start gives the multi-wave kernels'
+                                      //  bits; full body has no registers for it -- its NaN case takes pc_produce below, whose
+                                      //  sin / cos differ from the block path's in the last place)
+                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, false>(A, sh, S, cost, b, lane, k, kk, live, kg
+#if defined(CCV_STAMP)
+                                                                                       , ST
+#endif
+                );
+        }
         if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
         // ---------------- their distance to the window
         const int nv = min(kTU, nstates - b * kTU);
