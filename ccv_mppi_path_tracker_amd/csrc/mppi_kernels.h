@@ -107,16 +107,17 @@ __device__ __forceinline__ RolloutArgs with_resident_pose(const RolloutArgs& Ak)
 
 // window coefficients -> LDS, padded to a multiple of 4 points with c = +inf (never the minimum)
 template <class SH>
-__device__ __forceinline__ void stage_window(const RolloutArgs& A, const Window& Wk, SH& sh, int nthreads) {
+__device__ __forceinline__ void stage_window(const RolloutArgs& A, const Window& Wk, SH& sh, int nthreads,
+                                             const int tid = threadIdx.x) {   // (tid: 0 .. nthreads-1 over the staging threads)
     const int H = A.H, H4 = (H + 3) & ~3;
     if (A.frame) {
         const Window& W = A.frame->W;
-        for (int j = threadIdx.x; j < H4; j += nthreads) {
+        for (int j = tid; j < H4; j += nthreads) {
             sh.ab[j] = j < H ? make_double2(W.a[j], W.b[j]) : make_double2(0.0, 0.0);
             sh.c[j] = j < H ? W.c[j] : INFINITY;
         }
     } else {
-        for (int j = threadIdx.x; j < H4; j += nthreads) {
+        for (int j = tid; j < H4; j += nthreads) {
             sh.ab[j] = j < H ? make_double2(Wk.a[j], Wk.b[j]) : make_double2(0.0, 0.0);
             sh.c[j] = j < H ? Wk.c[j] : INFINITY;
         }

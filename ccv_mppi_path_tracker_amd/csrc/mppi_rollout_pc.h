@@ -86,14 +86,15 @@ struct PcShared {
 // vector loads) every block of 8 steps exposes one cache-miss latency -- ~1500 cycles, measured -- on the producer chain.
 // Returns whether one of the values this thread staged is NaN (see clampd_fast).
 template <int MODEL, class SH>
-__device__ __forceinline__ bool pc_stage_nominal(const RolloutArgs& A, SH& sh, const int nthreads) {
+__device__ __forceinline__ bool pc_stage_nominal(const RolloutArgs& A, SH& sh, const int nthreads,
+                                                 const int tid = threadIdx.x) {   // (tid: 0 .. nthreads-1)
     const int R = (A.H - 1) * udim_of(MODEL);
     bool bad = false;
     if (A.pending_vec) {
         // K sharded over devices: the all-reduced [sum w, sum w*u] has not been divided yet -- do it here (the division
         // k_apply_partials would do, bit for bit) instead of spending a kernel launch on 100 quotients
         const double S = A.pending_vec[0];
-        for (int j = threadIdx.x; j < R + 8; j += nthreads) {
+        for (int j = tid; j < R + 8; j += nthreads) {
             const double v = j < R ? A.pending_vec[1 + j] / S : 0.0;
             sh.nom[j] = v;
             bad |= v != v;
@@ -102,10 +103,10 @@ __device__ __forceinline__ bool pc_stage_nominal(const RolloutArgs& A, SH& sh, c
                 A.nominal_used[j] = v;
             }
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) A.stats_w[0] = S;
+        if (blockIdx.x == 0 && tid == 0) A.stats_w[0] = S;
         return bad;
     }
-    for (int j = threadIdx.x; j < R + 8; j += nthreads) {
+    for (int j = tid; j < R + 8; j += nthreads) {
         const double v = j < R ? A.nominal[j] : 0.0;
         sh.nom[j] = v;
         bad |= v != v;

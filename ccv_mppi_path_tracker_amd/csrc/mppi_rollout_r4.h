@@ -85,6 +85,28 @@ struct R4Shared {
     int seq[8];
 };
 
+// The normals of time block b -> LDS (noise wave).  The same grouping of the Philox calls as pc_produce_batched (4 | 3 + 3):
+// a normal does not depend on it.
+template <int MODEL, class SH>
+__device__ __forceinline__ void r4_noise_block(const RolloutArgs& A, SH& sh, const int b, const int lane, const uint32_t kg) {
+    constexpr int UD = udim_of(MODEL), NCALL = kTU * UD / 4;
+    auto group = [&](auto C0_, auto CN_) {
+        constexpr int C0 = decltype(C0_)::value, CN = decltype(CN_)::value;
+        float z[4 * CN];
+        pc_block_normals<MODEL, C0, CN>(A, b, kg, z);
+#pragma unroll
+        for (int i = 0; i < 4 * CN; ++i) sh.zs[b & 1][4 * C0 + i][lane] = z[i];
+    };
+    using std::integral_constant;
+    if constexpr (NCALL == 4) {
+        group(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+    } else {
+        static_assert(NCALL == 6, "steering: 3 + 3 Philox calls");
+        group(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+        group(integral_constant<int, 3>{}, integral_constant<int, 3>{});
+    }
+}
+
 // The per-lane sample indices, made afresh where a role (or the epilogue) needs them: five values that are live from the
 // first instruction to the last would otherwise be spilled at 128 registers (the asm statement keeps the compiler from
 // merging the copies back into one).
@@ -115,23 +137,34 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     const RolloutArgs A = with_resident_pose(Ak);
     const int H = A.H;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x < 8) sh.seq[threadIdx.x] = 0;
-    __syncthreads();   // (the sequence numbers are zero before seq[5], the "NaN in the warm start" flag, can be raised)
-    if constexpr (COST) stage_window(A, Wk, sh, kR4Waves * 64);
-    if constexpr (MODE == MODE_FUSED) {
-        if (pc_stage_nominal<MODEL>(A, sh, kR4Waves * 64)) sh.seq[5] = 1;
-    }
-    // (every role keeps its own cost part and drops it into LDS at the end of its loop: one variable across the four
-    //  branches and the epilogue gets spilled)
     const int nblocks = (H + kTU - 1) / kTU;
     const int nstates = H;   // states that reach the path cost (dd:199)
     // blocks whose 8 steps all carry controls: their normals come from the noise wave (the last, partial block is the
     // dynamics wave's own: pc_produce)
     const int nfull = MODE == MODE_FUSED ? (H - 1) / kTU : 0;
+    int* const seq_noise = &sh.seq[0];
+    if (threadIdx.x < 8) sh.seq[threadIdx.x] = 0;
+    __syncthreads();   // (the sequence numbers are zero before anything is published or seq[5], the "NaN in u*" flag, raised)
+    if constexpr (MODE == MODE_FUSED) {
+        // the window and the warm start are staged by three waves; the noise wave needs neither and makes the normals of block
+        // 0 meanwhile -- the dynamics wave waits for both anyway, now for the longer of the two instead of their sum
+        if (wv == 0) {
+            if (nfull > 0) {
+                const R4Lane L = r4_lane(A);
+                r4_noise_block<MODEL>(A, sh, 0, L.lane, L.kg);
+                pc_publish(seq_noise, 1);
+            }
+        } else {
+            const int tid = (int)threadIdx.x - 64;
+            stage_window(A, Wk, sh, (kR4Waves - 1) * 64, tid);
+            if (pc_stage_nominal<MODEL>(A, sh, (kR4Waves - 1) * 64, tid)) sh.seq[5] = 1;
+        }
+    } else {
+        if constexpr (COST) stage_window(A, Wk, sh, kR4Waves * 64);
+    }
     __syncthreads();
     // two-instruction clamps (clampd_fast): the host has checked sigma and the bounds, the staging found no NaN in u*
     const bool fast_clamp = MODE == MODE_FUSED && A.fast_clamp && __builtin_amdgcn_readfirstlane(sh.seq[5]) == 0;
-    int* const seq_noise = &sh.seq[0];
     int* const seq_ready = &sh.seq[1];
     int* const seq_dist = &sh.seq[2];
     int* const seq_store = &sh.seq[3];
@@ -152,32 +185,16 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     if (wv == 0) {
         // ---------------- noise wave
         if constexpr (MODE == MODE_FUSED) {
-            constexpr int NCALL = kTU * UD / 4;
             const R4Lane L = r4_lane(A);
             const int lane = L.lane;
             const uint32_t kg = L.kg;
-            for (int b = 0; b < nfull; ++b) {
+            for (int b = 1; b < nfull; ++b) {   // (block 0: above, beside the staging)
                 pc_rotate_priority(A, b);
                 if (b >= 2) {   // zs[b & 1] last held block b-2: the dynamics wave is through it, the store wave has loaded it
                     pc_wait_for(seq_ready, b - 1);
                     pc_wait_for(seq_store, b - 1);
                 }
-                // the same grouping of the Philox calls as pc_produce_batched (4 | 3 + 3): a normal does not depend on it
-                auto group = [&](auto C0_, auto CN_) {
-                    constexpr int C0 = decltype(C0_)::value, CN = decltype(CN_)::value;
-                    float z[4 * CN];
-                    pc_block_normals<MODEL, C0, CN>(A, b, kg, z);
-#pragma unroll
-                    for (int i = 0; i < 4 * CN; ++i) sh.zs[b & 1][4 * C0 + i][lane] = z[i];
-                };
-                using std::integral_constant;
-                if constexpr (NCALL == 4) {
-                    group(integral_constant<int, 0>{}, integral_constant<int, 4>{});
-                } else {
-                    static_assert(NCALL == 6, "steering: 3 + 3 Philox calls");
-                    group(integral_constant<int, 0>{}, integral_constant<int, 3>{});
-                    group(integral_constant<int, 3>{}, integral_constant<int, 3>{});
-                }
+                r4_noise_block<MODEL>(A, sh, b, lane, kg);
                 pc_publish(seq_noise, b + 1);
             }
         }
