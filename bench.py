@@ -47,7 +47,7 @@ def rollout_kernel_name(model, k_local, device):
                 "r4": "k_rollout_pc" if model == "full_body" else "k_rollout_r4", "solo": "k_rollout_solo"}.get(forced, forced)
     import torch
     cus = torch.cuda.get_device_properties(device).multi_processor_count
-    if (k_local + 63) // 64 > 4 * cus:
+    if (k_local + 63) // 64 > (4 if model == "full_body" else 5) * cus:
         return "k_rollout_solo"
     return "k_rollout_pc" if model == "full_body" else "k_rollout_r4"
 

@@ -695,7 +695,9 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
         int cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        h->solo = h->coop && !kenv && h->nblocks > 4 * cus;
+        // (round 2, four-wave kernel against one-wave kernel, diff drive, kernel us: K = 81 920 61.0 vs 64.2; 98 304 66.0 vs 64.3;
+        //  131 072 75.2 vs 71.0; 196 608 104 vs 99; steering 131 072 90.1 vs 84.0 -- the switch sits at five blocks per CU there)
+        h->solo = h->coop && !kenv && h->nblocks > (h->cfg.model == CCV_MPPI_FULL_BODY ? 4 : 5) * cus;
         if (h->coop && kenv && std::strcmp(kenv, "solo") == 0) h->solo = true;
     }
     // wave priorities (pc_rotate_priority): measured -4 us on the three-wave kernel (C2), -3 % on the two-wave one (C4), and
