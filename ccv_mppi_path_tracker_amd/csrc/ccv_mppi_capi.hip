@@ -99,6 +99,7 @@ struct ccv_mppi_handle {
     int lds_window = 1;
     int coop = 1;
     bool solo = false;   // fused iterations run k_rollout_solo (one wave per 64 samples) instead of coop's kernel
+    bool fast_clamp_allowed = true;   // clampd_fast (mppi_kernels.h) unless CCV_MPPI_FAST_CLAMP=0
     int prio_rotate = 0, cu_count = 256;   // pc_rotate_priority (mppi_rollout_pc.h)
     int prune = 0;                         // pc_prune_window (mppi_rollout_pc.h)
     double inj_absmax[CCV_MPPI_MAX_UDIM] = {0, 0, 0, 0, 0};   // largest |control| per dimension in the buffer (sampled: clamp bound)
@@ -169,7 +170,7 @@ void fill_args(const ccv_mppi_handle* h, RolloutArgs& A, const double* x0, doubl
     A.fast_clamp = std::isfinite(c.control_noise) ? 1 : 0;
     for (int d = 0; d < udim_of(c.model); ++d)
         if (!(c.u_min[d] <= c.u_max[d])) A.fast_clamp = 0;
-    if (std::getenv("CCV_MPPI_FAST_CLAMP") && std::atoi(std::getenv("CCV_MPPI_FAST_CLAMP")) == 0) A.fast_clamp = 0;   // (experiments)
+    if (!h->fast_clamp_allowed) A.fast_clamp = 0;   // (CCV_MPPI_FAST_CLAMP=0: tests, experiments)
     const bool roll_off = (c.flags & CCV_MPPI_FLAG_ROLL_OFF) != 0;
     A.w_path = c.path_weight;
     A.w_v = c.v_weight;
@@ -710,6 +711,7 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     // results do not depend on it, tested).
     h->prune = h->coop ? 1 : 0;
     if (const char* pv = std::getenv("CCV_MPPI_PRUNE")) h->prune = std::strcmp(pv, "0") != 0;
+    if (const char* pv = std::getenv("CCV_MPPI_FAST_CLAMP")) h->fast_clamp_allowed = std::strcmp(pv, "0") != 0;
 
     auto bail = [&](int code, const char* what, hipError_t e) {
         fail(h, code, what, e);

@@ -1,9 +1,10 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-for K in 81920 98304 131072 196608; do
-  echo "K=$K"
-  BENCH_ARGS="--samples-per-gpu $K --steps 200 --warmup 20 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5h_$K 2 -- "default=X=1" "r4=CCV_MPPI_KERNEL=r4"
-done
-echo C3
-BENCH_ARGS="--workload C3 --samples-per-gpu 131072 --steps 100 --warmup 20 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5h_c3 2 -- "default=X=1" "r4=CCV_MPPI_KERNEL=r4"
+mkdir -p gpurun_out/final2
+timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/final2/pytest.txt 2>&1; echo pytest rc=$?
+tail -3 gpurun_out/final2/pytest.txt
+timeout -k 10 300 python3 bench.py > gpurun_out/final2/bench.json 2> gpurun_out/final2/bench.err; echo bench rc=$?
+python3 -c "
+import json; d=json.loads(open('gpurun_out/final2/bench.json').read()); r=d['roofline']
+print('%.3e rollouts/s  %.2f us/step  kernel %.2f us frac %.3f traffic %s closed loop %.1f' % (d['value'], 1e3*d['ms_per_step'], r['kernel_avg_us'], r['frac'], r['traffic'], d['closed_loop']['us_per_tick']))"
