@@ -608,6 +608,26 @@ def test_read_back_ranges_and_errors():
         lean.read_candidates()
 
 
+@pytest.mark.parametrize("wl,K,H", [("C2", 1000, 50), ("C3", 640, 50), ("C2", 300, 128), ("C4", 256, 80)])
+def test_iteration_without_the_state_store(wl, K, H):
+    """CCV_MPPI_FLAG_NO_STATE_STORE drops the K x H (x, y) buffer (bench.py --no-state-store); everything else of an
+    iteration -- costs, weights, controls, the update -- must be the same bits as with it, over two iterations (the four-wave
+    kernel's store wave counts its outstanding stores for the epilogue's early re-read: a different count without the states)."""
+    w = configs.workload(wl)
+    p = w.params.with_(num_samples=K, horizon=H)
+    path = helpers.oracle_path(w.path)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    full, lean = MPPIController(p), MPPIController(p, no_state_store=True)
+    for it in range(2):
+        uf = full.iterate(state, p.dt, xr, yr, yaw[0], 13, it, want_stats=False)
+        ul = lean.iterate(state, p.dt, xr, yr, yaw[0], 13, it, want_stats=False)
+        np.testing.assert_array_equal(uf, ul)
+    np.testing.assert_array_equal(full.read_costs(), lean.read_costs())
+    np.testing.assert_array_equal(full.read_weights(), lean.read_weights())
+    np.testing.assert_array_equal(full.read_controls(), lean.read_controls())
+
+
 # --------------------------------------------------------------------------------------------------------------
 # full BASELINE sizes: size-independent properties
 # --------------------------------------------------------------------------------------------------------------

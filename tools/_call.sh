@@ -1,10 +1,5 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/final2
-timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/final2/pytest.txt 2>&1; echo pytest rc=$?
-tail -3 gpurun_out/final2/pytest.txt
-timeout -k 10 300 python3 bench.py > gpurun_out/final2/bench.json 2> gpurun_out/final2/bench.err; echo bench rc=$?
-python3 -c "
-import json; d=json.loads(open('gpurun_out/final2/bench.json').read()); r=d['roofline']
-print('%.3e rollouts/s  %.2f us/step  kernel %.2f us frac %.3f traffic %s closed loop %.1f' % (d['value'], 1e3*d['ms_per_step'], r['kernel_avg_us'], r['frac'], r['traffic'], d['closed_loop']['us_per_tick']))"
+mkdir -p gpurun_out/final3
+timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "state_store or read_back" > gpurun_out/final3/pytest.txt 2>&1; echo rc=$?; tail -4 gpurun_out/final3/pytest.txt
