@@ -126,6 +126,18 @@ __device__ __forceinline__ R4Lane r4_lane(const RolloutArgs& A) {
     return L;
 }
 
+// Diagnostic builds (-DCCV_STAMP, tools/stamps_r4.py): six 100 MHz timestamps per workgroup -- [0] kernel entry, [1] the
+// dynamics wave has published block 0, [2] its loop is through, [3] the distance wave's loop is through, [4] wave 0 is past
+// the barrier, [5] wave 0 is through the epilogue.
+#if defined(CCV_STAMP)
+#define R4_STAMP(slot)                                                                                                \
+    do {                                                                                                              \
+        if (A.dbg && blockIdx.x < 4096) A.dbg[64 + blockIdx.x * 6 + (slot)] = __builtin_amdgcn_s_memrealtime();       \
+    } while (0)
+#else
+#define R4_STAMP(slot) do {} while (0)
+#endif
+
 template <int MODEL, int MODE>
 __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutArgs Ak, const Window Wk) {
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
@@ -137,6 +149,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     const RolloutArgs A = with_resident_pose(Ak);
     const int H = A.H;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wv == 0) R4_STAMP(0);
     const int nblocks = (H + kTU - 1) / kTU;
     const int nstates = H;   // states that reach the path cost (dd:199)
     // blocks whose 8 steps all carry controls: their normals come from the noise wave (the last, partial block is the
@@ -254,7 +267,9 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                 if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
             }
             pc_publish(seq_ready, b + 1);
+            if (b == 0) R4_STAMP(1);
         }
+        R4_STAMP(2);
         if constexpr (COST) sh.cost[1][lane] = cost;
         if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
         early_fetch();
@@ -286,6 +301,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
 #endif
             if (!taken) pc_publish(seq_dist, b + 1);   // (nothing of this block reaches the path cost)
         }
+        R4_STAMP(3);
         if constexpr (COST) sh.cost[2][lane] = cost;
     } else {
         // ---------------- store wave: normals (MODE_FUSED) and states (not in MODE_COST) of block b, LDS -> registers ->
@@ -365,6 +381,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         // the one barrier of the kernel: every wave is through its loop (the store wave with all its stores acknowledged),
         // the cost parts are in LDS, and p / ab / c / zs are dead
         pc_barrier_lds();
+        if (wv == 0) R4_STAMP(4);
         if ((MODE != MODE_FUSED || wv >= 2) && mcount > 0) r4_fetch0(A, upd, rows, kk);
         const double total = ((sh.cost[0][lane] + sh.cost[1][lane]) + sh.cost[2][lane]) + sh.cost[3][lane];
         const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
@@ -377,6 +394,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
             pc_reduce_rows<kR4RB, MODEL>(A, sh, buf, upd, rows, mcount, wgt, lane, kk, fast_clamp);
             if (wv == kR4Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
         }
+        if (wv == 0) R4_STAMP(5);
     }
 }
 
