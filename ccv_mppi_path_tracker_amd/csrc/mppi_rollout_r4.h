@@ -137,6 +137,15 @@ __device__ __forceinline__ R4Lane r4_lane(const RolloutArgs& A) {
 #else
 #define R4_STAMP(slot) do {} while (0)
 #endif
+// -DCCV_STAMP=2: the six slots cover the start of the kernel instead -- [0] entry, [1] first barrier passed, [2] staging
+// barrier passed, [3] block 0's normals published, [4] the dynamics wave has them, [5] it has published block 0.
+#if defined(CCV_STAMP) && CCV_STAMP + 0 == 2
+#define R4_STAMP_LOOP(slot) do {} while (0)
+#define R4_STAMP_FILL(slot) R4_STAMP(slot)
+#else
+#define R4_STAMP_LOOP(slot) R4_STAMP(slot)
+#define R4_STAMP_FILL(slot) do {} while (0)
+#endif
 
 template <int MODEL, int MODE>
 __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutArgs Ak, const Window Wk) {
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     const RolloutArgs A = with_resident_pose(Ak);
     const int H = A.H;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wv == 0) R4_STAMP(0);
+    if (wv == 0) R4_STAMP(0);   // (both stamp sets)
     const int nblocks = (H + kTU - 1) / kTU;
     const int nstates = H;   // states that reach the path cost (dd:199)
     // blocks whose 8 steps all carry controls: their normals come from the noise wave (the last, partial block is the
@@ -158,6 +167,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     int* const seq_noise = &sh.seq[0];
     if (threadIdx.x < 8) sh.seq[threadIdx.x] = 0;
     __syncthreads();   // (the sequence numbers are zero before anything is published or seq[5], the "NaN in u*" flag, raised)
+    if (wv == 1) R4_STAMP_FILL(1);
     if constexpr (MODE == MODE_FUSED) {
         // the window and the warm start are staged by three waves; the noise wave needs neither and makes the normals of block
         // 0 meanwhile -- the dynamics wave waits for both anyway, now for the longer of the two instead of their sum
@@ -166,6 +176,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                 const R4Lane L = r4_lane(A);
                 r4_noise_block<MODEL>(A, sh, 0, L.lane, L.kg);
                 pc_publish(seq_noise, 1);
+                R4_STAMP_FILL(3);
             }
         } else {
             const int tid = (int)threadIdx.x - 64;
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         if constexpr (COST) stage_window(A, Wk, sh, kR4Waves * 64);
     }
     __syncthreads();
+    if (wv == 1) R4_STAMP_FILL(2);
     // two-instruction clamps (clampd_fast): the host has checked sigma and the bounds, the staging found no NaN in u*
     const bool fast_clamp = MODE == MODE_FUSED && A.fast_clamp && __builtin_amdgcn_readfirstlane(sh.seq[5]) == 0;
     int* const seq_ready = &sh.seq[1];
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
             }
             if (b < nfull) {
                 pc_wait_for(seq_noise, b + 1);
+                if (b == 0) R4_STAMP_FILL(4);
                 // (two instantiations: a NaN in the warm start is rare, but its results are to be the other kernels' bits too)
                 if (fast_clamp)
                     pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true>(A, sh, S, cost, b, lane, k, kk, live, kg
@@ -267,9 +280,12 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                 if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
             }
             pc_publish(seq_ready, b + 1);
-            if (b == 0) R4_STAMP(1);
+            if (b == 0) {
+                R4_STAMP_LOOP(1);
+                R4_STAMP_FILL(5);
+            }
         }
-        R4_STAMP(2);
+        R4_STAMP_LOOP(2);
         if constexpr (COST) sh.cost[1][lane] = cost;
         if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
         early_fetch();
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
 #endif
             if (!taken) pc_publish(seq_dist, b + 1);   // (nothing of this block reaches the path cost)
         }
-        R4_STAMP(3);
+        R4_STAMP_LOOP(3);
         if constexpr (COST) sh.cost[2][lane] = cost;
     } else {
         // ---------------- store wave: normals (MODE_FUSED) and states (not in MODE_COST) of block b, LDS -> registers ->
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         // the one barrier of the kernel: every wave is through its loop (the store wave with all its stores acknowledged),
         // the cost parts are in LDS, and p / ab / c / zs are dead
         pc_barrier_lds();
-        if (wv == 0) R4_STAMP(4);
+        if (wv == 0) R4_STAMP_LOOP(4);
         if ((MODE != MODE_FUSED || wv >= 2) && mcount > 0) r4_fetch0(A, upd, rows, kk);
         const double total = ((sh.cost[0][lane] + sh.cost[1][lane]) + sh.cost[2][lane]) + sh.cost[3][lane];
         const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
             pc_reduce_rows<kR4RB, MODEL>(A, sh, buf, upd, rows, mcount, wgt, lane, kk, fast_clamp);
             if (wv == kR4Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
         }
-        if (wv == 0) R4_STAMP(5);
+        if (wv == 0) R4_STAMP_LOOP(5);
     }
 }
 

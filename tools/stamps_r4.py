@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic (never shipped): timeline of the four-wave kernel's workgroups from a -DCCV_STAMP build (_abl/lib_stamp.so):
-when the pipeline is filled, when the loops end, how long barrier and epilogue take.   python tools/stamps_r4.py [workload]"""
+"""Diagnostic (never shipped): timeline of the four-wave kernel's workgroups from a -DCCV_STAMP build (_abl/lib_stamp.so, made by
+`python tools/ablate.py stamp=-DCCV_STAMP`): when the pipeline is filled, when the loops end, how long barrier and epilogue take;
+with a -DCCV_STAMP=2 build and STAMP_SET=fill: the start of the kernel in detail.   python tools/stamps_r4.py [workload]"""
 import ctypes as C
 import os
 import sys
@@ -29,6 +30,9 @@ g.lib.ccv_mppi_debug_blocks(g._h, blk, nb)
 b = np.array(list(blk), dtype=np.float64).reshape(nb, 6)
 t = (b - b[:, 0].min()) / 100.0     # us since the first workgroup's entry
 names = ["entry", "block 0 published (dynamics)", "dynamics loop end", "distance loop end", "past the barrier", "epilogue end"]
+if os.environ.get("STAMP_SET") == "fill":   # a -DCCV_STAMP=2 build
+    names = ["entry", "first barrier passed", "staging barrier passed", "block 0's normals published", "dynamics wave has them",
+             "block 0 published (dynamics)"]
 print("%s: %d workgroups; us since the first workgroup's entry: mean  [min .. max]" % (wl, nb))
 for i, n in enumerate(names):
     print("  %-30s %6.2f  [%6.2f .. %6.2f]" % (n, t[:, i].mean(), t[:, i].min(), t[:, i].max()))
@@ -36,4 +40,5 @@ d = t - t[:, :1]
 print("per workgroup, us since its own entry: mean")
 for i, n in enumerate(names[1:], 1):
     print("  %-30s %6.2f" % (n, d[:, i].mean()))
-print("  barrier wait after the distance loop %5.2f   epilogue %5.2f" % ((t[:, 4] - t[:, 3]).mean(), (t[:, 5] - t[:, 4]).mean()))
+if not os.environ.get("STAMP_SET"):
+    print("  barrier wait after the distance loop %5.2f   epilogue %5.2f" % ((t[:, 4] - t[:, 3]).mean(), (t[:, 5] - t[:, 4]).mean()))
