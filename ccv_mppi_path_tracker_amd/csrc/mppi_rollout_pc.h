@@ -118,14 +118,18 @@ __device__ __forceinline__ bool pc_stage_nominal(const RolloutArgs& A, SH& sh, c
 // The control of row n = t * u_dim + d from its normal: the samplers' arithmetic (double(z) * sigma + mean, clamp, steer_off),
 // so the same bits as the value the rollout used.  D = n % u_dim is a template argument: the clamp bounds then are scalar
 // kernel arguments (a run-time dimension would cost an integer division and two LDS reads with their waits per value).
-template <int MODEL, int D, bool FASTCLAMP = false, class SH>
-__device__ __forceinline__ double pc_control_from_normal(const RolloutArgs& A, const SH& sh, const float z, const int n) {
-    double v = (double)z * A.sigma + sh.nom[n];
+template <int MODEL, int D, bool FASTCLAMP = false>
+__device__ __forceinline__ double pc_control_from_normal_at(const RolloutArgs& A, const float z, const double nominal) {
+    double v = (double)z * A.sigma + nominal;
     v = clampd_as<FASTCLAMP>(v, arg5<D>(A.umin), arg5<D>(A.umax));
     if constexpr (MODEL == CCV_MPPI_FULL_BODY && D == 2) {
         if (A.steer_off) v = 0.0;   // fb:517
     }
     return v;
+}
+template <int MODEL, int D, bool FASTCLAMP = false, class SH>
+__device__ __forceinline__ double pc_control_from_normal(const RolloutArgs& A, const SH& sh, const float z, const int n) {
+    return pc_control_from_normal_at<MODEL, D, FASTCLAMP>(A, z, sh.nom[n]);
 }
 
 // The candidate states x, y are written once and not read again by this kernel: streaming (non-temporal) stores keep
@@ -960,52 +964,75 @@ __device__ __forceinline__ void pc_update_fetch(const RolloutArgs& A, T (&v)[kUp
 // RB rows at a time through the wave-private LDS buffer `buf` (RB * 65 doubles): every lane drops w*u for each row, then
 // lane (r, q) adds 16 of the 64 entries of row r and two shuffles finish the row.  (The caller has fetched the first
 // chunk into v.)
-template <int RB, int MODEL, class SH, class T, class ROWS>
+// LOOP (four-wave kernel): the batches of a chunk are a real loop whose body always works on v[0 .. RB-1]; after a batch the
+// register array is shifted down by RB (48 moves).  Unrolled, the epilogue is 2-3 KB of straight-line code per wave that runs
+// once, and the instruction cache is cold for every line of it: tools/stamps_r4.py found 1.6 us per batch of 12 rows, the time
+// of ~20 line fetches, not of 150 instructions.  (The one- and two-wave kernels go round their unrolled chunk several times.)
+template <int RB, int MODEL, bool LOOP = false, class SH, class T, class ROWS>
 __device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, const SH& sh, double* buf, T (&v)[kUpdCH], const ROWS& rows,
                                                const int mcount, const double wgt, const int lane, const int kk,
                                                const bool fast_clamp = false) {   // (wave-uniform: see clampd_fast)
     static_assert(RB <= 16 && kUpdCH % RB == 0, "batch size");
     constexpr int STRIDE = kPcSamples + 1;   // padded row: lanes (r, q) hit different banks
     const int rr = lane >> 2, q = lane & 3;
+    // one batch: products of rows base .. base+RB-1 (held in v[V0 .. V0+RB-1]) -> LDS -> row sums -> partial
+    auto batch = [&](auto V0_, const int base) {
+        constexpr int V0 = decltype(V0_)::value;
+        const int nrows = min(RB, mcount - base);
+        // the warm start of the batch's rows first, all reads in flight together: read row by row between the LDS writes
+        // below, every row waits out an LDS round trip (the compiler keeps LDS reads behind LDS writes: 12 x lgkmcnt(0) per
+        // batch, ~1.6 us per batch with sixteen waves of a CU in their epilogues at once)
+        double nomv[RB];
+        if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) nomv[r] = sh.nom[rows.row(min(base + r, mcount - 1))];
+        }
+        auto products = [&](auto FAST_) {
+            constexpr bool FAST = decltype(FAST_)::value;
+            static_for<RB>([&](auto RR) {
+                constexpr int r = decltype(RR)::value;
+                if constexpr (std::is_same<T, float>::value) {
+                    // the row's control dimension: rows are dealt in units of ROWS::BR (a multiple of u_dim), chunks of kUpdCH
+                    // (= 60: a multiple of 2, 3 and 5) and batches of RB, so it only depends on the position inside the batch
+                    constexpr int UD = udim_of(MODEL);
+                    static_assert(ROWS::BR % UD == 0 && kUpdCH % UD == 0 && (!LOOP || RB % UD == 0), "row dealing vs control dimension");
+                    constexpr int d = (V0 + r) % UD;
+                    // (rows past the end: clamped above, never summed)
+                    buf[r * STRIDE + lane] = wgt * pc_control_from_normal_at<MODEL, d, FAST>(A, v[V0 + r], nomv[r]);
+                } else {
+                    buf[r * STRIDE + lane] = wgt * v[V0 + r];
+                }
+            });
+        };
+        if (std::is_same<T, float>::value && fast_clamp) products(std::true_type{});
+        else products(std::false_type{});
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed (wave-private buffer)
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+        if (rr < nrows) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc += buf[rr * STRIDE + q * 16 + i];
+        }
+        acc += dpp_move<kDppXor1>(acc);   // the four lanes of a row are one quad
+        acc += dpp_move<kDppXor2>(acc);
+        if (rr < nrows && q == 0) A.partial[(size_t)rows.row(base + rr) * A.nparts + blockIdx.x] = acc;
+        __builtin_amdgcn_wave_barrier();
+    };
     for (int chunk0 = 0; chunk0 < mcount; chunk0 += kUpdCH) {
         if (chunk0 != 0) pc_update_fetch(A, v, rows, chunk0, mcount, kk);
-        static_for<kUpdCH / RB>([&](auto BB) {
-            constexpr int bb = decltype(BB)::value;
-            const int base = chunk0 + bb * RB;
-            const int nrows = min(RB, mcount - base);
-            if (nrows > 0) {
-                auto products = [&](auto FAST_) {
-                    constexpr bool FAST = decltype(FAST_)::value;
-                    static_for<RB>([&](auto RR) {
-                        constexpr int r = decltype(RR)::value;
-                        if constexpr (std::is_same<T, float>::value) {
-                            // the row's control dimension: rows are dealt in units of ROWS::BR (a multiple of u_dim) and chunks
-                            // of kUpdCH (= 60: a multiple of 2, 3 and 5), so it only depends on the position inside the chunk
-                            constexpr int UD = udim_of(MODEL);
-                            static_assert(ROWS::BR % UD == 0 && kUpdCH % UD == 0, "row dealing vs control dimension");
-                            constexpr int d = (bb * RB + r) % UD;
-                            const int row = rows.row(min(base + r, mcount - 1));   // (rows past the end: clamped, never summed)
-                            buf[r * STRIDE + lane] = wgt * pc_control_from_normal<MODEL, d, FAST>(A, sh, v[bb * RB + r], row);
-                        } else {
-                            buf[r * STRIDE + lane] = wgt * v[bb * RB + r];
-                        }
-                    });
-                };
-                if (std::is_same<T, float>::value && fast_clamp) products(std::true_type{});
-                else products(std::false_type{});
-                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed (wave-private buffer)
-                __builtin_amdgcn_wave_barrier();
-                double acc = 0.0;
-                if (rr < nrows) {
+        if constexpr (LOOP) {
+#pragma clang loop unroll(disable)
+            for (int base = chunk0; base < min(mcount, chunk0 + kUpdCH); base += RB) {
+                batch(std::integral_constant<int, 0>{}, base);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc += buf[rr * STRIDE + q * 16 + i];
-                }
-                acc += dpp_move<kDppXor1>(acc);   // the four lanes of a row are one quad
-                acc += dpp_move<kDppXor2>(acc);
-                if (rr < nrows && q == 0) A.partial[(size_t)rows.row(base + rr) * A.nparts + blockIdx.x] = acc;
-                __builtin_amdgcn_wave_barrier();
+                for (int i = 0; i + RB < kUpdCH; ++i) v[i] = v[i + RB];
             }
-        });
+        } else {
+            static_for<kUpdCH / RB>([&](auto BB) {
+                constexpr int bb = decltype(BB)::value;
+                if (chunk0 + bb * RB < mcount) batch(std::integral_constant<int, bb * RB>{}, chunk0 + bb * RB);
+            });
+        }
     }
 }
 

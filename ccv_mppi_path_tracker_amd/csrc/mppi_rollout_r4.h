@@ -139,7 +139,11 @@ __device__ __forceinline__ R4Lane r4_lane(const RolloutArgs& A) {
 #endif
 // -DCCV_STAMP=2: the six slots cover the start of the kernel instead -- [0] entry, [1] first barrier passed, [2] staging
 // barrier passed, [3] block 0's normals published, [4] the dynamics wave has them, [5] it has published block 0.
-#if defined(CCV_STAMP) && CCV_STAMP + 0 == 2
+#if defined(CCV_STAMP) && CCV_STAMP + 0 == 4   // (the epilogue: [0] wave 0 past the barrier, [1] / [3] wave 0 / 2 has its weight,
+                                               //  [2] / [4] / [5] wave 0 / 2 / 3 done; STAMP_SET=epi)
+#define R4_STAMP_LOOP(slot) do {} while (0)
+#define R4_STAMP_FILL(slot) do {} while (0)
+#elif defined(CCV_STAMP) && CCV_STAMP + 0 == 2
 #define R4_STAMP_LOOP(slot) do {} while (0)
 #define R4_STAMP_FILL(slot) R4_STAMP(slot)
 #else
@@ -158,7 +162,9 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     const RolloutArgs A = with_resident_pose(Ak);
     const int H = A.H;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if !(defined(CCV_STAMP) && CCV_STAMP + 0 == 4)
     if (wv == 0) R4_STAMP(0);   // (both stamp sets)
+#endif
     const int nblocks = (H + kTU - 1) / kTU;
     const int nstates = H;   // states that reach the path cost (dd:199)
     // blocks whose 8 steps all carry controls: their normals come from the noise wave (the last, partial block is the
@@ -398,6 +404,9 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         // the cost parts are in LDS, and p / ab / c / zs are dead
         pc_barrier_lds();
         if (wv == 0) R4_STAMP_LOOP(4);
+#if defined(CCV_STAMP) && CCV_STAMP + 0 == 4
+        if (wv == 0 && A.dbg && blockIdx.x < 4096) A.dbg[64 + blockIdx.x * 6 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
         if ((MODE != MODE_FUSED || wv >= 2) && mcount > 0) r4_fetch0(A, upd, rows, kk);
         const double total = ((sh.cost[0][lane] + sh.cost[1][lane]) + sh.cost[2][lane]) + sh.cost[3][lane];
         const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
@@ -405,12 +414,22 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
             A.cost[k] = total;
             A.w[k] = wgt;
         }
+#if defined(CCV_STAMP) && CCV_STAMP + 0 == 4
+        {
+            double keep = wgt;
+            asm volatile("" : "+v"(keep));
+            if (A.dbg && blockIdx.x < 4096 && (wv == 0 || wv == 2)) A.dbg[64 + blockIdx.x * 6 + (wv == 0 ? 1 : 3)] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
         if (A.fuse_update) {
             double* buf = &sh.p[0][0][0][0] + wv * (kR4RB * (kPcSamples + 1));
-            pc_reduce_rows<kR4RB, MODEL>(A, sh, buf, upd, rows, mcount, wgt, lane, kk, fast_clamp);
+            pc_reduce_rows<kR4RB, MODEL, true>(A, sh, buf, upd, rows, mcount, wgt, lane, kk, fast_clamp);
             if (wv == kR4Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
         }
         if (wv == 0) R4_STAMP_LOOP(5);
+#if defined(CCV_STAMP) && CCV_STAMP + 0 == 4
+        if (A.dbg && blockIdx.x < 4096 && wv != 1) A.dbg[64 + blockIdx.x * 6 + (wv == 0 ? 2 : wv == 2 ? 4 : 5)] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 }
 

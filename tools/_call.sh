@@ -1,5 +1,5 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/r5l
-STAMP_SET=fill3 timeout -k 10 300 python3 tools/stamps_r4.py C2 > gpurun_out/r5l/fill3_c2.txt 2>&1; cat gpurun_out/r5l/fill3_c2.txt
+mkdir -p gpurun_out/r5n
+STAMP_SET=epi timeout -k 10 300 python3 tools/stamps_r4.py C2 > gpurun_out/r5n/epi_c2.txt 2>&1; cat gpurun_out/r5n/epi_c2.txt

@@ -30,6 +30,8 @@ g.lib.ccv_mppi_debug_blocks(g._h, blk, nb)
 b = np.array(list(blk), dtype=np.float64).reshape(nb, 6)
 t = (b - b[:, 0].min()) / 100.0     # us since the first workgroup's entry
 names = ["entry", "block 0 published (dynamics)", "dynamics loop end", "distance loop end", "past the barrier", "epilogue end"]
+if os.environ.get("STAMP_SET") == "epi":   # a -DCCV_STAMP=4 build
+    names = ["wave 0 past the barrier", "wave 0 has its weight", "wave 0 done", "wave 2 has its weight", "wave 2 done", "wave 3 done"]
 if os.environ.get("STAMP_SET") == "fill":   # a -DCCV_STAMP=2 build
     names = ["entry", "first barrier passed", "staging barrier passed", "block 0's normals published", "dynamics wave has them",
              "block 0 published (dynamics)"]
