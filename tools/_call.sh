@@ -1,12 +1,9 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/final4
-timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/final4/pytest.txt 2>&1; echo pytest rc=$?
-tail -3 gpurun_out/final4/pytest.txt
-timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final4/smoke.txt 2>&1; echo smoke rc=$?; tail -1 gpurun_out/final4/smoke.txt
-timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > gpurun_out/final4/bench_driver.json 2> gpurun_out/final4/bench.err; echo bench rc=$?
-python3 -c "
-import json; d=json.loads(open('gpurun_out/final4/bench_driver.json').read()); r=d['roofline']
-print('%.3e rollouts/s  %.2f us/step  kernel %.2f us frac %.3f traffic %s closed loop %.1f' % (d['value'], 1e3*d['ms_per_step'], r['kernel_avg_us'], r['frac'], r['traffic'], d['closed_loop']['us_per_tick']))"
-timeout -k 10 600 python3 tests/soak_determinism.py 3000 > gpurun_out/final4/soak.txt 2>&1; tail -4 gpurun_out/final4/soak.txt
+mkdir -p gpurun_out/r5q
+timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/r5q/pytest.txt 2>&1; rc=$?
+tail -3 gpurun_out/r5q/pytest.txt
+[ $rc -eq 0 ] || exit 1
+BENCH_ARGS="--steps 400 --warmup 20 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5q 3 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
+BENCH_ARGS="--workload C3 --steps 200 --warmup 20 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5q_c3 2 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
