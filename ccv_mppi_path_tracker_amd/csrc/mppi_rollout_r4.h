@@ -1,21 +1,21 @@
 // Four-wave rollout kernel for gfx950 (MI355X): one workgroup = 64 samples = noise wave + dynamics wave + distance wave +
 // store wave.
 //
-// Why a fourth wave.  At K = 65 536 the three-wave kernel (mppi_rollout_r3.h) puts three waves on every SIMD, one of each
-// role, and the SIMD's vector unit is busy for little more than half of the kernel time: every wave is a long dependent
-// chain that waits out its own latencies, three of them do not cover each other, and a workgroup advances at the pace of
-// its longest chain -- the producer, ~3.6 k issue cycles per block of 8 steps, half of them the Philox / Box-Muller noise
-// that nothing in the block depends on but the controls' first operation.  Here the producer is cut in two:
+// The three-wave kernel's producer (mppi_rollout_r3.h) is cut in two:
 //
 //   wave 0 (noise)      the fp32 normals of time block b (Philox4x32-10 + Box-Muller: integer / fp32 work only) -> LDS
 //   wave 1 (dynamics)   controls from the normals, dynamics and control costs of block b-1; (x, y) -> LDS
 //   wave 2 (distance)   min over the window points of the squared distance for the states of block b-2
 //   wave 3 (store)      normals and states of block b-2: LDS -> HBM
 //
-// so that the longest chain of a workgroup is ~2.5 k cycles per block, and with four waves per workgroup a SIMD holds four
-// waves (128 VGPRs each).  The hardware deals the waves of consecutive workgroups to the SIMDs of a CU in a fixed rotation
-// (tools/microbench/wave_placement.hip: with four workgroups of four waves per CU every SIMD receives wave 0, 1, 2 and 3 of
-// four different workgroups), so every SIMD again runs one wave of each role.
+// Why a fourth wave -- not for more overlap: at K = 65 536 the kernel's time is the time its instructions take to issue,
+// whichever wave issues them (moving work between the waves changes nothing, profiles/
+// r02_ab_same_box.txt r4c, r5j).  But (1) the hardware deals the waves of consecutive workgroups to the SIMDs of a CU in a
+// fixed rotation (tools/microbench/wave_placement.hip): with four workgroups of four waves per CU every SIMD receives wave
+// 0, 1, 2 and 3 of four different workgroups, one wave of each role, in every process -- with three waves per workgroup
+// that depends on the dispatch, and the steering workload ran at 52 or 61 us by process; and (2) the noise and the dynamics
+// wave are through their loops early, which lets the epilogue's re-read start before the kernel's barrier, and the noise
+// wave needs nothing that is staged, which lets block 0's normals be made beside the staging.
 // Hand-offs are LDS sequence numbers as in the three-wave kernel.  Arithmetic, noise and the summation order inside a row
 // are those of k_rollout_pc / k_rollout_r3: the results are bit-identical.
 #pragma once
