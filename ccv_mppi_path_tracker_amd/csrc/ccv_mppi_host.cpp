@@ -51,9 +51,7 @@ void spec_sincos(double x, double& s, double& c) {
     pc = std::fma(z, pc, 2.48015872894767294178e-05);
     pc = std::fma(z, pc, -1.38888888888741095749e-03);
     pc = std::fma(z, pc, 4.16666666666666019037e-02);
-    const double hz = 0.5 * z;
-    const double w = 1.0 - hz;
-    const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+    const double cr = std::fma(z, std::fma(z, pc, -0.5), 1.0);
     const int q = static_cast<int>(fn);
     const double sa = (q & 1) ? cr : sr;
     const double ca = (q & 1) ? sr : cr;

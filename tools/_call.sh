@@ -1,9 +1,10 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/final5
-export HSA_ENABLE_IPC_MODE_LEGACY=0
-CCV_BENCH_DEVICE=0 CCV_BENCH_BACKEND=gloo timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29551 bench.py --gpus 2 --steps 50 --warmup 5 > gpurun_out/final5/x2.json 2> gpurun_out/final5/x2.err; echo rc=$?
-python3 -c "
-import json; d=json.loads(open('gpurun_out/final5/x2.json').read()); print(d['value'], d['ms_per_step'], d['config']['exchange'])"
-timeout -k 10 500 python3 tests/closed_loop_eval.py > gpurun_out/final5/closed_loop_eval.txt 2>&1; echo rc=$?; tail -12 gpurun_out/final5/closed_loop_eval.txt
+mkdir -p gpurun_out/r5r
+timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r5r/pytest.txt 2>&1; rc=$?
+tail -3 gpurun_out/r5r/pytest.txt
+[ $rc -eq 0 ] || exit 1
+BENCH_ARGS="--workload C3 --steps 200 --warmup 20 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5r_c3 3 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
+BENCH_ARGS="--workload C4 --steps 100 --warmup 10 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5r_c4 2 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
+BENCH_ARGS="--steps 400 --warmup 20 --no-cpu-baseline --no-closed-loop-leg" timeout -k 10 300 bash tools/ab_bench.sh r5r 2 -- "new=X=1" "prev=CCV_MPPI_LIB=$R/_abl/lib_prev.so"
