@@ -12,6 +12,7 @@ stays resident in HBM and evolves from step to step.  Nothing under oracle/ is t
 `cpu_baseline` leg (rank 0, N=1), which times the CPU restatement of the reference loop on the host.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N ...          (no launcher: the parent starts the N ranks itself, before anything touches a GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -201,6 +202,171 @@ def latest_pmc_traffic(workload_name):
     return best
 
 
+def measure_workload(amd, torch, configs, name, steps, warmup, stream, device, prime_s=0.3):
+    """One more single-GPU BASELINE workload (C3, C4) measured the way the headline is: untimed priming, `warmup` steps,
+    `steps` timed steps between two device synchronisations, then a 256-launch pass with hipEvents on the rollout kernel's
+    dispatch.  Returns the entry of `other_workloads`."""
+    w = configs.workload(name)
+    p = w.params
+    ctl = amd.MPPIController(p, device=device)
+    ctl.set_stream(stream.cuda_stream)
+    inputs = script_inputs(amd, w, 64)
+
+    def step(i):
+        s, xr, yr, yaw0 = inputs[i % len(inputs)]
+        ctl.iterate_enqueue(s, p.dt, xr, yr, yaw0, 42, i)
+
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < prime_s or n < 256:
+        for _ in range(64):
+            step(n)
+            n += 1
+    torch.cuda.synchronize()
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ctl.timing_enable(True, every=1)
+    ctl.timing_read(reset=True)
+    for i in range(256):
+        step(warmup + steps + i)
+    torch.cuda.synchronize()
+    roll_us, iter_us, n_ev = ctl.timing_read(reset=True)
+    ctl.timing_enable(False)
+    finite = bool(np.all(np.isfinite(ctl.get_nominal())))
+    ctl.close()
+    B, _ = algorithmic_bytes(p.horizon, p.udim)
+    k_us = roll_us / max(n_ev, 1)
+    traffic = latest_pmc_traffic(name)
+    return {"workload": "%s: %s, u_dim=%d, launch parameters" % (w.name, w.description, p.udim),
+            "value": p.num_samples * steps / el, "unit": "rollouts/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * el / steps, "primed_iterations": n, "finite": finite,
+            "kernel": rollout_kernel_name(p.model, p.num_samples, device), "kernel_avg_us": k_us,
+            "kernel_launches_averaged": int(n_ev), "iteration_avg_us": iter_us / max(n_ev, 1),
+            "algorithmic_bytes_per_launch": B * p.num_samples,
+            "frac": B * p.num_samples / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us > 0 else None,
+            "traffic": traffic,
+            "measured_traffic_frac": (traffic / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (traffic and k_us > 0) else None}
+
+
+def defaults_leg(amd, device, with_cpu=True):
+    """The operating points the reference itself runs at: dd K = 1 000 (dd:18-19), sd K = 1 000
+    (launch/steering_diff_drive_mppi.launch:11), fb K = 10 000 (fb:9-10), H = 15, inside a 100 ms tick (dd:334) -- what a node
+    that drops the library in gets per tick.  Timed around ONE C call per tick, ccv_mppi_node_run_once() of the ROS-free
+    mirror (csrc/host/mppi_node.cpp: run()'s body, dd:346-361), closed loop on the host plant:
+      blocking_iterate    calc_RefPath() on the host + blocking ccv_mppi_iterate              (use_fused_)
+      stage_wise_4_calls  the four stage-wise calls INTEGRATION.md section 2 pastes into the method bodies
+      device_prologue     window built on the device + iteration + u* back
+    and, through ccv_mppi_iterate_enqueue, the back-to-back rate without a host wait.  The CPU figure is the oracle
+    (mt19937 mode) at the same size on one host core."""
+    from ccv_mppi_path_tracker_amd import configs
+    from ccv_mppi_path_tracker_amd.node import ControllerNode
+    out = {}
+    cases = (("dd_K1000_H15", "diff_drive", {}, "sinusoid", configs.diff_drive_defaults(1000, 15)),
+             ("sd_K1000_H15", "steering_diff_drive", {"num_samples": 1000}, "sinusoid", configs.steering_defaults(1000, 15)),
+             ("fb_K10000_H15", "full_body", {}, "dkan", configs.full_body_defaults(10000, 15)))
+    for key, model, params, path, p in cases:
+        px, py = amd.make_path(path)
+        res = {"what": "%s defaults, K=%d H=%d, %s path" % (model, p.num_samples, p.horizon, path)}
+        for mode, kw in (("blocking_iterate", dict(fused=True)), ("stage_wise_4_calls", dict(fused=False)),
+                         ("device_prologue", dict(fused=True, device_prologue=True))):
+            node = ControllerNode(model, params, device=device, **kw)
+            node.set_path(px, py)
+            s = np.zeros(5)
+            s[0], s[1] = px[0], py[0]
+            lat = []
+            for i in range(260):
+                node.set_state(s)
+                t0 = time.perf_counter()
+                cmd = node.run_once(p.dt)
+                lat.append(time.perf_counter() - t0)
+                u0 = node.optimal_solution()[0]
+                s[:p.nstate] = amd.plant_step(model, s[:p.nstate], u0, p.dt)
+                if np.hypot(px[-1] - s[0], py[-1] - s[1]) < 1.0 or cmd is None:   # end of the course: start over
+                    s[:] = 0.0
+                    s[0], s[1] = px[0], py[0]
+            node.close()
+            res[mode + "_us_median"] = 1e6 * float(np.median(lat[60:]))
+        # back to back, no host wait: n enqueues, one synchronisation
+        ctl = amd.MPPIController(p, device=device)
+        inputs = script_inputs(amd, configs.Workload(key, p, path), 16)
+        for rep in range(2):
+            n = 512
+            t0 = time.perf_counter()
+            for i in range(n):
+                s0, xr, yr, yaw0 = inputs[i % len(inputs)]
+                ctl.iterate_enqueue(s0, p.dt, xr, yr, yaw0, 42, i)
+            ctl.synchronize()
+            res["iterate_enqueue_us_per_iteration"] = 1e6 * (time.perf_counter() - t0) / n
+        ctl.timing_enable(True, every=1)
+        ctl.timing_read(reset=True)
+        for i in range(64):
+            s0, xr, yr, yaw0 = inputs[i % len(inputs)]
+            ctl.iterate_enqueue(s0, p.dt, xr, yr, yaw0, 42, i)
+        ctl.synchronize()
+        r_us, i_us, n_ev = ctl.timing_read(reset=True)
+        ctl.close()
+        res["rollout_kernel_us"] = r_us / max(n_ev, 1)
+        res["device_iteration_us"] = i_us / max(n_ev, 1)
+        res["kernel"] = rollout_kernel_name(p.model, p.num_samples, device)
+        if not with_cpu:
+            out[key] = res
+            continue
+        # the oracle at the same size (one core): a cpu_baseline leg, the only kind of use bench.py makes of oracle/
+        from oracle import oracle_lib as O
+        o = O.Oracle(p.model, p.num_samples, p.horizon, p.control_noise, p.lam, p.v_ref, p.u_min, p.u_max,
+                     path_weight=p.path_weight, v_weight=p.v_weight, zmp_weight=p.zmp_weight, roll_v_weight=p.roll_v_weight,
+                     back_weight=p.back_weight, yaw_weight=p.yaw_weight, roll_off=p.roll_off, steer_off=p.steer_off)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 1.0 or n < 3:
+            s0, xr, yr, yaw0 = inputs[n % len(inputs)]
+            o.iterate(s0, p.dt, xr, yr, yaw0, seed=42 + n, rng="mt19937")
+            n += 1
+        res["cpu_oracle_ms_per_iteration_1_core"] = 1e3 * (time.perf_counter() - t0) / n
+        out[key] = res
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, 127.0.0.1 rendezvous), let rank 0 print the JSON line on the inherited
+    stdout, and return the first non-zero exit code (the others are then stopped by their exact PIDs).  Called before torch
+    or the HIP library is imported: the parent never touches a GPU and nothing is ever exec'ed over a process that has."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              env=dict(base, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    rc, alive = 0, set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()
+                t_stop = time.time()
+                while any(procs[q].poll() is None for q in alive) and time.time() - t_stop < 15.0:
+                    time.sleep(0.05)
+                for q in alive:
+                    if procs[q].poll() is None:
+                        procs[q].kill()
+        time.sleep(0.02)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,7 +377,7 @@ def main():
     ap.add_argument("--path", default=None, help="reference path instead of the workload's: straight | sinusoid | dkan")
     ap.add_argument("--dt", type=float, default=None,
                     help="loop period instead of the workload's 0.1 s (the node measures it, dd:346-348): beyond |w|max*dt = pi/4 "
-                         "(0.3927 s at the C2 limits) the host routes the call to the plain kernel (not the headline)")
+                         "(0.3927 s at the C2 limits) the host launches the kernel's full-range sin/cos instantiation (not the headline)")
     ap.add_argument("--closed-loop", action="store_true",
                     help="not the headline: the device-resident closed loop (pose advanced by u*[0] and the window rebuilt "
                          "on the device every step; the workload's path generator with the course extended so that it never ends)")
@@ -223,7 +389,12 @@ def main():
     ap.add_argument("--no-closed-loop-leg", action="store_true", help="skip the device-resident closed-loop figure of the default line")
     ap.add_argument("--no-state-store", action="store_true", help="skip the KxH x,y buffer (not the headline)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the C3 / C4 legs of the default line")
+    ap.add_argument("--no-defaults-leg", action="store_true", help="skip the reference-default operating points (K = 1 000 / 10 000, H = 15)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -329,6 +500,9 @@ def main():
         ctl.set_nominal(zeros)
         # (key name: `rccl_us_per_step` only when the process group really is RCCL; the one-device rehearsal uses gloo)
         ar_key = "rccl_us_per_step" if backend == "nccl" else "%s_allreduce_us_per_step" % backend
+        # what the process group itself reports (not the launcher's environment): a SCALE line proves with these two keys
+        # that RCCL saw N ranks
+        exchange_info.update(world_seen=int(dist.get_world_size()), backend_seen=str(dist.get_backend()))
         exchange_info.update(backend=backend, **{ar_key: time_256(rccl)})
         if good:
             ctl.set_nominal(zeros)
@@ -441,15 +615,26 @@ def main():
             "primed_iterations": primed_iterations,
             "config": {"workload": "%s: %s, u_dim=%d, launch parameters" % (w.name, w.description.replace(
                 "K=%d" % p.num_samples, "K=%d" % k_total), p.udim),
-                       "samples_per_gpu": k_local, "horizon": p.horizon, "sharding": "K over %d GPU(s)" % world, **({"exchange": exchange_used} if exchange_used else {}),
+                       "samples_per_gpu": k_local, "horizon": p.horizon, "sharding": "K over %d GPU(s)" % world,
+                       # untimed set-up iterations before the W warm-up steps (the host side of the first several hundred
+                       # launches of a process is slow): the steady state `value` is quoted in
+                       "primed_iterations": primed_iterations,
+                       **({"exchange": exchange_used} if exchange_used else {}),
                        **({"exchange_detail": exchange_info} if exchange_info else {}),
                        "state_store": not args.no_state_store,
                        **({"closed_loop": "device-resident: plant + get_CurrentIndex + calc_RefPath on the device, "
                                           "%d path poses" % len(cl_px)} if args.closed_loop else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         # `frac` divides the CONTRACT's algorithmic bytes (fp64 controls written and re-read)
+                         # by the kernel time; the kernel really moves `traffic` bytes (it stores the fp32 normals and
+                         # re-derives the controls), i.e. measured_traffic_frac of the 8 TB/s -- what limits it is VALU issue
+                         # (profiles/*_pmc_summary.txt: SQ_ACTIVE_INST_VALU), not HBM
+                         "measured_traffic_frac": (traffic / roll_avg_s / 1e9 / HBM_PEAK_GBS) if (traffic and roll_avg_s > 0) else None,
+                         "traffic_source": "rocprofv3 --pmc pass of the same workload and kernel, committed under profiles/ (not measured by this run)" if traffic else None,
+                         "limiter": "valu-issue (contract bound: hbm)",
                          "kernel": rollout_kernel_name(p.model, k_local, local_rank) if args.dt is None else
-                                   rollout_kernel_name(p.model, k_local, local_rank) + " (or k_rollout_cost beyond the small-turn gate)",
+                                   rollout_kernel_name(p.model, k_local, local_rank) + " (its full-range sin/cos instantiation beyond the small-turn gate)",
                          "kernel_avg_us": 1e6 * roll_avg_s,
                          "kernel_launches_averaged": int(n_ev),
                          "algorithmic_bytes_per_launch": B_roll * k_local,
@@ -487,6 +672,15 @@ def main():
                                   "path_error_rms_m": float(np.sqrt(np.mean(d * d))), "path_error_max_m": float(d.max())}
         if world == 1 and not args.closed_loop and args.workload == "C2" and not args.no_closed_loop_leg:
             out["closed_loop"] = closed_loop_leg(amd, torch, ctl, w, seed)
+        headline = (world == 1 and not args.closed_loop and args.workload == "C2" and args.samples_per_gpu is None
+                    and args.dt is None and args.path is None and not args.no_state_store)
+        if headline and not args.no_other_workloads:
+            # BASELINE configs[2] and configs[3], measured like the headline (their own handles; C2's is released first)
+            ctl.close()
+            out["other_workloads"] = {"C3": measure_workload(amd, torch, configs, "C3", 100, 10, stream, local_rank),
+                                      "C4": measure_workload(amd, torch, configs, "C4", 60, 10, stream, local_rank)}
+        if headline and not args.no_defaults_leg:
+            out["defaults"] = defaults_leg(amd, local_rank, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
             out["cpu_baseline_reference_shaped"] = cpu_baseline(w, budget_s=10.0, by_value=True)

@@ -69,7 +69,9 @@ struct ccv_mppi_handle {
     ExchangeBox* box_peer[kMaxRanks] = {nullptr};   // every rank's box as mapped here ([xchg_rank] = d_box)
     bool box_opened[kMaxRanks] = {false};           // mapped with hipIpcOpenMemHandle (to be closed)
     double* d_xvec = nullptr;                       // reduced [sum w, sum w*u]
-    int32_t* d_xflag = nullptr;                     // device-side "a peer timed out" flag (sticky)
+    int32_t* h_xflag = nullptr;                     // "a peer timed out" flag: pinned, host-mapped memory the update kernel writes
+    int32_t* d_xflag = nullptr;                     // ... and its device address (sticky until the exchange is released)
+    double xchg_timeout_s = 10.0;                   // (what the message says)
     int xchg_world = 0, xchg_rank = 0;
     bool xchg_connected = false;
     bool box_fine_grained = false;                  // the box is fine-grained (device-coherent) memory
@@ -99,6 +101,7 @@ struct ccv_mppi_handle {
     int lds_window = 1;
     int coop = 1;
     bool solo = false;   // fused iterations run k_rollout_solo (one wave per 64 samples) instead of coop's kernel
+    bool wide_turn = false;   // this launch: diff drive beyond |w|max dt = pi/4 -> the full-range sin / cos instantiation
     bool fast_clamp_allowed = true;   // clampd_fast (mppi_kernels.h) unless CCV_MPPI_FAST_CLAMP=0
     int prio_rotate = 0, cu_count = 256;   // pc_rotate_priority (mppi_rollout_pc.h)
     int prune = 0;                         // pc_prune_window (mppi_rollout_pc.h)
@@ -139,6 +142,18 @@ int fail(ccv_mppi_handle* h, int code, const char* what, hipError_t e = hipSucce
     } while (0)
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// The caller's current device is put back when an entry point that had to switch to the handle's device returns (on error
+// paths too): a process that drives several devices must not find its current device changed behind its back.
+struct DeviceGuard {
+    int prev = -1, mine = -1;
+    explicit DeviceGuard(int device) : mine(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != mine) (void)hipSetDevice(prev);
+    }
+};
 
 int ensure_scratch(ccv_mppi_handle* h, size_t bytes) {
     if (bytes <= h->scratch_bytes) return CCV_MPPI_OK;
@@ -232,6 +247,16 @@ void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const 
     if (h->solo && h->coop && mode == MODE_FUSED) {
         // one wave per 64 samples (mppi_rollout_solo.h): K provides two or more such waves per SIMD
         const dim3 sgrid((h->K + kPcSamples - 1) / kPcSamples), sblock(kPcSamples);
+        if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
+            if (h->wide_turn) {
+                if (h->ev_kernel_start)
+                    hipExtLaunchKernelGGL((k_rollout_solo<MODEL, MODE_FUSED, true>), sgrid, sblock, 0, h->stream, h->ev_kernel_start,
+                                          h->ev_kernel_stop, 0, A, W);
+                else
+                    hipLaunchKernelGGL((k_rollout_solo<MODEL, MODE_FUSED, true>), sgrid, sblock, 0, h->stream, A, W);
+                return;
+            }
+        }
         if (h->ev_kernel_start)
             hipExtLaunchKernelGGL((k_rollout_solo<MODEL, MODE_FUSED>), sgrid, sblock, 0, h->stream, h->ev_kernel_start,
                                   h->ev_kernel_stop, 0, A, W);
@@ -243,6 +268,16 @@ void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const 
     if (h->coop == 3) {
         // four-wave kernel (mppi_rollout_r4.h)
         const dim3 cgrid((h->K + kPcSamples - 1) / kPcSamples), cblock(kR4Waves * 64);
+        if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
+            if (mode == MODE_FUSED && h->wide_turn) {
+                if (h->ev_kernel_start)
+                    hipExtLaunchKernelGGL((k_rollout_r4<MODEL, MODE_FUSED, true>), cgrid, cblock, 0, h->stream, h->ev_kernel_start,
+                                          h->ev_kernel_stop, 0, A, W);
+                else
+                    hipLaunchKernelGGL((k_rollout_r4<MODEL, MODE_FUSED, true>), cgrid, cblock, 0, h->stream, A, W);
+                return;
+            }
+        }
         if (mode == MODE_FUSED && h->ev_kernel_start) {
             hipExtLaunchKernelGGL((k_rollout_r4<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, h->ev_kernel_start,
                                   h->ev_kernel_stop, 0, A, W);
@@ -333,11 +368,15 @@ int materialize_controls(ccv_mppi_handle* h) {
     return CCV_MPPI_OK;
 }
 
-// k_rollout_pc uses a branch-free sin/cos that is valid for |angle| <= kFastTrigLimit.  Every heading a sample can
+// The cooperative kernels use a branch-free sin/cos that is valid for |angle| <= kFastTrigLimit.  Every heading a sample can
 // reach is bounded by the start angle plus (H-1) steps at the largest control magnitude, so the decision is made here,
 // once per call; anything else (huge or non-finite angles, unbounded injected controls) runs the plain
 // one-sample-per-lane kernel with OCML's sincos.
-bool fast_trig_safe(const ccv_mppi_handle* h, const RolloutArgs& A, int mode) {
+// Returns kTrigUnsafe (plain kernel), kTrigSafe, or kTrigWide: diff drive, fused iteration, four-wave or one-wave kernel,
+// every heading inside the range but a turn per step beyond pi/4 -- the instantiation that evaluates sin / cos of every
+// heading in full (as the steering model's does) instead of advancing them by the step's turn.
+enum : int { kTrigUnsafe = 0, kTrigSafe = 1, kTrigWide = 2 };
+int fast_trig_safe(const ccv_mppi_handle* h, const RolloutArgs& A, int mode) {
     const int ud = h->udim;
     double umax[CCV_MPPI_MAX_UDIM];
     for (int d = 0; d < ud; ++d) {
@@ -351,23 +390,30 @@ bool fast_trig_safe(const ccv_mppi_handle* h, const RolloutArgs& A, int mode) {
         bound = std::fmax(bound, std::fabs(A.x0[4]) + steps * umax[4]);
     }
     // diff drive advances (sin, cos) of the heading by the step's turn angle: needs |w| dt <= pi/4 (fast_trig.h)
-    if (h->cfg.model == CCV_MPPI_DIFF_DRIVE && !(umax[1] * std::fabs(A.dt) <= kSmallTurnLimit)) return false;
+    bool wide = false;
+    if (h->cfg.model == CCV_MPPI_DIFF_DRIVE && !(umax[1] * std::fabs(A.dt) <= kSmallTurnLimit)) {
+        if (!(mode == MODE_FUSED && (h->coop == 3 || h->solo))) return kTrigUnsafe;   // (the stage-wise and the experiment kernels have no wide form)
+        wide = true;
+    }
     // full body: the same for yaw, roll and pitch, and the direction angle itself is evaluated without range reduction
     if (h->cfg.model == CCV_MPPI_FULL_BODY) {
         if (!(umax[1] * std::fabs(A.dt) <= kSmallTurnLimit) || !(umax[3] * std::fabs(A.dt) <= kSmallTurnLimit) ||
             !(umax[4] * std::fabs(A.dt) <= kSmallTurnLimit) || !(umax[2] <= kSmallTurnLimit))
-            return false;
+            return kTrigUnsafe;
         // ... and divides by dt through its reciprocal (div_uniform, mppi_kernels.h): nothing may overflow or vanish on the way
-        if (!(std::fabs(A.dt) >= 1.0e-100 && std::fabs(A.dt) <= 1.0e100) || !(umax[0] <= 1.0e100) || !(umax[3] <= 1.0e100)) return false;
+        if (!(std::fabs(A.dt) >= 1.0e-100 && std::fabs(A.dt) <= 1.0e100) || !(umax[0] <= 1.0e100) || !(umax[3] <= 1.0e100)) return kTrigUnsafe;
     }
-    return bound <= kFastTrigLimit;   // false for NaN
+    if (!(bound <= kFastTrigLimit)) return kTrigUnsafe;   // (also for NaN)
+    return wide ? kTrigWide : kTrigSafe;
 }
 
 int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A_in, const Window& W, int mode) {
     RolloutArgs A = A_in;
     const int saved = h->coop;
-    if (h->coop && !fast_trig_safe(h, A, mode)) h->coop = 0;
-    struct Restore { ccv_mppi_handle* h; int v; ~Restore() { h->coop = v; } } restore{h, saved};
+    const int trig = h->coop ? fast_trig_safe(h, A, mode) : kTrigUnsafe;
+    if (h->coop && trig == kTrigUnsafe) h->coop = 0;
+    h->wide_turn = trig == kTrigWide;
+    struct Restore { ccv_mppi_handle* h; int v; ~Restore() { h->coop = v; h->wide_turn = false; } } restore{h, saved};
     // the production kernel also reduces its workgroup's share of sum w and sum w*u (no second pass over the controls);
     // the underflow-safe MIN_SHIFT mode needs the global minimum first and keeps the separate update kernels
     A.fuse_update = (h->coop && mode != MODE_ROLLOUT && !(h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT)) ? 1 : 0;
@@ -525,7 +571,7 @@ int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const dou
     if (resident) {
         std::memset(&W, 0, sizeof(W));
         A.frame = h->d_frame;
-        if (!h->coop || !fast_trig_safe(h, A, MODE_FUSED))
+        if (!h->coop || fast_trig_safe(h, A, MODE_FUSED) == kTrigUnsafe)
             return fail(h, CCV_MPPI_ERR_STATE, "the resident loop needs the cooperative kernels and bounded pose angles");
     } else {
         fill_window(h, W, x0, x_ref, y_ref);
@@ -624,7 +670,8 @@ void exchange_release(ccv_mppi_handle* h) {
         (void)hipFree(h->d_box);
     }
     if (h->d_xvec) (void)hipFree(h->d_xvec);
-    if (h->d_xflag) (void)hipFree(h->d_xflag);
+    if (h->h_xflag) (void)hipHostFree(h->h_xflag);
+    h->h_xflag = nullptr;
     if (h->pending_vec == h->d_xvec) h->pending_vec = nullptr;
     h->d_box = nullptr;
     h->d_xvec = nullptr;
@@ -633,14 +680,18 @@ void exchange_release(ccv_mppi_handle* h) {
     h->xchg_world = h->xchg_rank = 0;
 }
 
-// After a synchronisation: did the exchange kernel give up waiting for a peer?  (sticky: the controls are NaN from then on)
+// After a synchronisation: did the exchange kernel give up waiting for a peer?  The flag lives in pinned host-mapped memory
+// (the kernel stores to it once, system scope, in the rare case): reading it costs no copy and no extra synchronisation.
+// Sticky: the controls are NaN from then on; releasing the exchange (ccv_mppi_destroy, or a failed set-up) frees it and a
+// new ccv_mppi_exchange_create starts from a cleared one.
 int exchange_check(ccv_mppi_handle* h) {
-    if (!h->d_xflag) return CCV_MPPI_OK;
-    int32_t flag = 0;
-    HIP_TRY(h, hipMemcpy(&flag, h->d_xflag, sizeof(flag), hipMemcpyDeviceToHost));
-    if (flag)
-        return fail(h, CCV_MPPI_ERR_TIMEOUT, "direct exchange: a peer's partial vector did not arrive within 10 s; the controls are NaN "
-                                            "from that iteration on (destroy the handles and set the exchange up again)");
+    if (!h->h_xflag) return CCV_MPPI_OK;
+    if (*static_cast<volatile int32_t*>(h->h_xflag)) {
+        char msg[256];
+        std::snprintf(msg, sizeof(msg), "direct exchange: a peer's partial vector did not arrive within %.3g s; the controls are NaN "
+                                        "from that iteration on (destroy the handles and set the exchange up again)", h->xchg_timeout_s);
+        return fail(h, CCV_MPPI_ERR_TIMEOUT, msg);
+    }
     return CCV_MPPI_OK;
 }
 }  // namespace
@@ -914,6 +965,7 @@ int ccv_mppi_exchange_create(ccv_mppi_handle* h, int32_t world, int32_t rank, vo
     if (h->cfg.flags & CCV_MPPI_FLAG_MIN_SHIFT)
         return fail(h, CCV_MPPI_ERR_INVALID_ARG, "MIN_SHIFT needs a cross-device min; not supported with partials");
     if (h->d_box) return fail(h, CCV_MPPI_ERR_STATE, "exchange already created");
+    const DeviceGuard guard(h->cfg.device);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     // Fine-grained memory: a peer's stores become visible to a kernel that is already running on the owner.  Ordinary
     // (coarse-grained) device memory guarantees that only inside one device, so it is accepted as a fall-back only when
@@ -943,8 +995,11 @@ int ccv_mppi_exchange_create(ccv_mppi_handle* h, int32_t world, int32_t rank, vo
     if ((e = hipMemset(box, 0, sizeof(ExchangeBox))) != hipSuccess) return undo(CCV_MPPI_ERR_HIP, "hipMemset(box)", e);
     if ((e = hipMalloc(&h->d_xvec, (size_t)(h->R + 1) * sizeof(double))) != hipSuccess) return undo(CCV_MPPI_ERR_ALLOC, "hipMalloc(xvec)", e);
     if ((e = hipMemset(h->d_xvec, 0, (size_t)(h->R + 1) * sizeof(double))) != hipSuccess) return undo(CCV_MPPI_ERR_HIP, "hipMemset(xvec)", e);
-    if ((e = hipMalloc(&h->d_xflag, sizeof(int32_t))) != hipSuccess) return undo(CCV_MPPI_ERR_ALLOC, "hipMalloc(xflag)", e);
-    if ((e = hipMemset(h->d_xflag, 0, sizeof(int32_t))) != hipSuccess) return undo(CCV_MPPI_ERR_HIP, "hipMemset(xflag)", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->h_xflag), sizeof(int32_t), hipHostMallocMapped)) != hipSuccess)
+        return undo(CCV_MPPI_ERR_ALLOC, "hipHostMalloc(xflag)", e);
+    *h->h_xflag = 0;
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_xflag), h->h_xflag, 0)) != hipSuccess)
+        return undo(CCV_MPPI_ERR_HIP, "hipHostGetDevicePointer(xflag)", e);
     if ((e = hipDeviceSynchronize()) != hipSuccess) return undo(CCV_MPPI_ERR_HIP, "hipDeviceSynchronize", e);
     blob.pid = (int32_t)getpid();
     blob.device = h->cfg.device;
@@ -958,6 +1013,7 @@ int ccv_mppi_exchange_create(ccv_mppi_handle* h, int32_t world, int32_t rank, vo
         const long ms = std::atol(tv);
         if (ms > 0) h->xchg_timeout_ticks = (unsigned long long)ms * 100000ull;
     }
+    h->xchg_timeout_s = (double)h->xchg_timeout_ticks * 1.0e-8;   // 100 MHz ticks
     h->box_fine_grained = blob.fine_grained != 0;
     h->xchg_world = world;
     h->xchg_rank = rank;
@@ -975,6 +1031,7 @@ int ccv_mppi_exchange_connect(ccv_mppi_handle* h, const void* ipc_handles) {
     if (!ipc_handles) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "ipc_handles is null");
     if (!h->d_box) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_exchange_create first");
     if (h->xchg_connected) return fail(h, CCV_MPPI_ERR_STATE, "exchange already connected");
+    const DeviceGuard guard(h->cfg.device);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const ExchangeBlob* blobs = static_cast<const ExchangeBlob*>(ipc_handles);
     ExchangeBlob mine;
@@ -1093,9 +1150,9 @@ namespace {
 int resident_step(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, int32_t advance, bool normalise, double* vec_out,
                   bool exchange = false) {
     if (!h) return CCV_MPPI_ERR_INVALID_ARG;
-    // dt is the stride of the window index (dd:160-163): as ccv_mppi_calc_ref_path, only 0 < dt < inf is defined
+    // dt is the stride of the window index (dd:160-163): as ccv_mppi_calc_ref_path, only 0 <= dt < inf is defined
     const double stride = h->cfg.v_ref * dt / h->path_resolution;
-    if (!(dt > 0.0) || !std::isfinite(dt)) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "resident step: dt must be positive and finite");
+    if (!(dt >= 0.0) || !std::isfinite(dt)) return fail(h, CCV_MPPI_ERR_INVALID_ARG, "resident step: dt must be finite and not negative");
     if (!h->d_frame || !h->have_pose) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_resident_set_path and _set_pose first");
     if (!std::isfinite(stride) || stride < 0.0 || stride * h->H > 2.0e9)
         return fail(h, CCV_MPPI_ERR_INVALID_ARG, "resident step: v_ref * dt / resolution is not a usable window stride");
@@ -1127,7 +1184,7 @@ int resident_step(ccv_mppi_handle* h, double dt, uint64_t seed, uint64_t iter, i
         fill_args(h, chk, bounds, dt, 0.0, seed, iter);
         // k_advance itself takes sin / cos of the OLD heading (+ the steering command)
         const double heading_bound = h->res_angle_abs[0] + (c.model == CCV_MPPI_DIFF_DRIVE ? 0.0 : lim(2));
-        if (!h->coop || !fast_trig_safe(h, chk, MODE_FUSED) || !(heading_bound <= kFastTrigLimit))
+        if (!h->coop || fast_trig_safe(h, chk, MODE_FUSED) == kTrigUnsafe || !(heading_bound <= kFastTrigLimit))
             return fail(h, CCV_MPPI_ERR_STATE, "the resident loop needs the cooperative kernels and bounded pose angles / commands");
     }
     const bool fuse = h->fin_pending && !h->pending_vec;   // the last tick's update is still to be launched: together with this prologue

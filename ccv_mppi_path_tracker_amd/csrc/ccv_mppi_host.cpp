@@ -68,11 +68,13 @@ int ccv_mppi_calc_ref_path(const double* path_x, const double* path_y, int32_t n
                            double* yaw_ref) {
     if (!path_x || !path_y || !x_ref || !y_ref || !yaw_ref || n_path < 1 || horizon < 2) return CCV_MPPI_ERR_INVALID_ARG;
     // The window index start + i * stride is the truncation of a double (dd:160-163).  The node takes dt from its clock
-    // (dd:346-348); a non-positive or non-finite dt, v_ref or resolution makes that index negative or undefined (the
-    // reference then reads outside path_): refused here, and in the same way by the device-resident prologue.
+    // (dd:346-348); a negative or non-finite dt, v_ref or resolution makes that index negative or undefined (the reference
+    // then reads outside path_): refused here, and in the same way by the device-resident prologue.  dt == 0 (two ticks
+    // inside one clock tick) is defined -- stride 0, the window is H copies of the nearest pose, exactly what v_ref = 0
+    // gives -- and admitted.
     {
         const double stride_chk = v_ref * dt / resolution;
-        if (!(dt > 0.0) || !std::isfinite(stride_chk) || stride_chk < 0.0 || stride_chk * horizon > 2.0e9) return CCV_MPPI_ERR_INVALID_ARG;
+        if (!(dt >= 0.0) || !std::isfinite(stride_chk) || stride_chk < 0.0 || stride_chk * horizon > 2.0e9) return CCV_MPPI_ERR_INVALID_ARG;
     }
     const int start = nearest_index(path_x, path_y, n_path, cur_x, cur_y);
     // window stride in path indices; the index is the truncation of a double (dd:160-163)

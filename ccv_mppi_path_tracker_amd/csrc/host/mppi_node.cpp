@@ -57,9 +57,16 @@ int MPPIBase::get_CurrentIndex() {
 }
 
 void MPPIBase::calc_RefPath() {
-    current_index_ = ccv_mppi_calc_ref_path(path_.x.data(), path_.y.data(), (int32_t)path_.size(), current_state_.x,
-                                            current_state_.y, v_ref_, dt_, resolution_, horizon_, x_ref_.data(), y_ref_.data(),
-                                            yaw_ref_.data());
+    // (a negative return is a status code -- dt not positive and finite, an unusable stride: the window is NOT filled then;
+    //  the index of the last good window stays and the caller must not iterate against the stale window)
+    const int rc = ccv_mppi_calc_ref_path(path_.x.data(), path_.y.data(), (int32_t)path_.size(), current_state_.x,
+                                          current_state_.y, v_ref_, dt_, resolution_, horizon_, x_ref_.data(), y_ref_.data(),
+                                          yaw_ref_.data());
+    if (rc < 0) {
+        last_status_ = rc;
+        return;
+    }
+    current_index_ = rc;
 }
 
 void MPPIBase::sampling() { last_status_ = ccv_mppi_sample(handle_, seed_, iteration_); }
@@ -70,7 +77,9 @@ void MPPIBase::predict_States() {
 }
 
 void MPPIBase::calc_Weights() {
+    last_status_ = CCV_MPPI_OK;
     calc_RefPath();
+    if (last_status_ != CCV_MPPI_OK) return;   // no window: no weights, and run_once() publishes no command
     last_status_ = ccv_mppi_weights(handle_, x_ref_.data(), y_ref_.data(), yaw_ref_[0]);
 }
 
@@ -106,10 +115,12 @@ bool MPPIBase::run_once(double dt) {
         // it from the window like calc_RefPath() does (dd:176-179)
         for (int i = 1; i + 1 < horizon_; ++i) yaw_ref_[i] = std::atan2(y_ref_[i + 1] - y_ref_[i], x_ref_[i + 1] - x_ref_[i]);
     } else if (use_fused_) {
+        last_status_ = CCV_MPPI_OK;
         calc_RefPath();
         const double x0[5] = {current_state_.x, current_state_.y, current_state_.yaw, current_state_.roll, current_state_.pitch};
-        last_status_ = ccv_mppi_iterate(handle_, x0, dt_, x_ref_.data(), y_ref_.data(), yaw_ref_[0], seed_, iteration_,
-                                        optimal_solution.data(), &last_stats_);
+        if (last_status_ == CCV_MPPI_OK)   // (refused window: the tick is refused like on the device-prologue path)
+            last_status_ = ccv_mppi_iterate(handle_, x0, dt_, x_ref_.data(), y_ref_.data(), yaw_ref_[0], seed_, iteration_,
+                                            optimal_solution.data(), &last_stats_);
     } else {
         sampling();
         if (last_status_ == CCV_MPPI_OK) predict_States();

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize_exchange(const FinalizeArgs
     for (int r = 0; r < X.world; ++r) acc += lane_value(theirs, r);   // rank order on every device
     if (lane == 0) {
         X.reduced[slot] = ok ? acc : __builtin_nan("");
-        if (!ok && X.timeout_flag) *X.timeout_flag = 1;
+        if (!ok && X.timeout_flag) __hip_atomic_store(X.timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (pinned host memory)
     }
 }
 

@@ -393,7 +393,10 @@ __device__ __forceinline__ void pc_noise_ahead(const RolloutArgs& A, float (*slo
 // interleave -- a lone wave then issues back to back instead of waiting out each chain's latency.
 // ---------------------------------------------------------------------------------------------------------------
 // ZLDS (four-wave kernel): the block's normals are already in sh.zs, made by the noise wave.
-template <int MODEL, int MODE, class SH, bool ZLDS = false, bool FASTCLAMP = false>
+// WIDE (diff drive): sin / cos of every heading evaluated in full (fast_sincos_n, as steering does) instead of advanced by
+// the step's turn -- for loop periods beyond |w|max dt = pi/4, where the short polynomials of the rotation form are not
+// valid (the node measures dt, dd:346-348: one slow tick must not cost a different, twice as slow kernel).
+template <int MODEL, int MODE, class SH, bool ZLDS = false, bool FASTCLAMP = false, bool WIDE = false>
 __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh, PcState<MODEL>& S, double& cost,
                                                    const int b, const int lane, const int k, const int kk, const bool live,
                                                    const uint32_t kg
@@ -505,7 +508,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
 #pragma unroll
     for (int tt = 0; tt < kTU; ++tt) { sn[tt] = hd[tt] * 0.5; cs[tt] = 1.0 - hd[tt] * 0.25; }
 #else
-    if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
+    if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE && !WIDE) {
         // diff drive: the heading only ever changes by the step's turn w*dt, so its (sin, cos) are ADVANCED by that angle --
         // eight short independent polynomial pairs (no range reduction, no quadrant logic: the host admits this kernel
         // only for |w| dt <= pi/4) and a chain of eight 2x2 rotations, ~25 fp64 operations per step instead of ~40.

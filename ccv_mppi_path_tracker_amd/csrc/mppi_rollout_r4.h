@@ -151,12 +151,14 @@ __device__ __forceinline__ R4Lane r4_lane(const RolloutArgs& A) {
 #define R4_STAMP_FILL(slot) do {} while (0)
 #endif
 
-template <int MODEL, int MODE>
+// WIDE (diff drive, fused iteration): full-range sin / cos of every heading, for |w|max dt > pi/4 (pc_produce_batched)
+template <int MODEL, int MODE, bool WIDE = false>
 __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutArgs Ak, const Window Wk) {
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     constexpr bool COST = MODE != MODE_ROLLOUT;
     constexpr int UD = udim_of(MODEL);
     static_assert(!FB, "diff drive and steering only");
+    static_assert(!WIDE || (MODEL == CCV_MPPI_DIFF_DRIVE && MODE == MODE_FUSED), "the wide-turn form exists for the fused diff-drive iteration");
     __shared__ R4Shared<MODEL> sh;
     static_assert(offsetof(R4Shared<MODEL>, zs) + sizeof(sh.zs) >= kR4Waves * kR4RB * (kPcSamples + 1) * sizeof(double), "epilogue buffers");
     const RolloutArgs A = with_resident_pose(Ak);
@@ -264,13 +266,13 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                 if (b == 0) R4_STAMP_FILL(4);
                 // (two instantiations: a NaN in the warm start is rare, but its results are to be the other kernels' bits too)
                 if (fast_clamp)
-                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true>(A, sh, S, cost, b, lane, k, kk, live, kg
+                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg
 #if defined(CCV_STAMP)
                                                                          , ST
 #endif
                     );
                 else
-                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, false>(A, sh, S, cost, b, lane, k, kk, live, kg
+                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, false, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg
 #if defined(CCV_STAMP)
                                                                           , ST
 #endif

@@ -25,7 +25,7 @@ struct SoloShared {
     alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u*
 };
 
-template <int MODEL, int MODE>
+template <int MODEL, int MODE, bool WIDE = false>   // WIDE: see pc_produce_batched (diff drive beyond |w|max dt = pi/4)
 __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArgs Ak, const Window Wk) {
     static_assert(MODE == MODE_FUSED, "the stage-wise modes use k_rollout_pc");
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
         bool done = false;
         if (b * kTU + kTU <= H - 1) {
             if (fast_clamp)
-                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, true>(A, sh, S, cost, b, lane, k, kk, live, kg
+                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, true, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg
 #if defined(CCV_STAMP)
                                                                                       , ST
 #endif
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
             else if constexpr (!FB)   // (a second instantiation, so that a NaN in the warm start gives the multi-wave kernels'
                                       //  bits; full body has no registers for it -- its NaN case takes pc_produce below, whose
                                       //  sin / cos differ from the block path's in the last place)
-                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, false>(A, sh, S, cost, b, lane, k, kk, live, kg
+                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, false, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg
 #if defined(CCV_STAMP)
                                                                                        , ST
 #endif

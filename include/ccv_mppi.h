@@ -192,7 +192,7 @@ int ccv_mppi_iterate_exchange_enqueue(ccv_mppi_handle* h, const double* x0, doub
  * only) comes from the device atan2 and may differ from libm's in the last place.  v_ref and the horizon are the
  * handle's; `resolution` is the spacing of the path poses (resolution_, dd:160).  Needs the default (cooperative)
  * kernels.
- * dt must be positive and finite (it is the stride of the window index, dd:160-163; the reference's behaviour for anything
+ * dt must be finite and not negative (it is the stride of the window index, dd:160-163; the reference's behaviour for anything
  * else is undefined): CCV_MPPI_ERR_INVALID_ARG otherwise, as from ccv_mppi_calc_ref_path().
  * The plant takes yaw / roll / pitch modulo 2 pi once they leave +-1e4 rad (the real node reads them from tf in [-pi, pi]),
  * identically in ccv_mppi_plant_step(), so a loop of any length stays inside the range of the kernels' branch-free

@@ -23,8 +23,10 @@ extern "C" {
 /* Fills x_ref[H], y_ref[H], yaw_ref[H-1] (yaw_ref[H-1] is left untouched, as in the reference) and returns
  * current_index_ (>= 0), or a negative CCV_MPPI_ERR_* code.  The window index is the truncation of
  * current_index + i * v_ref * dt / resolution (dd:160-163) and the node takes dt from its clock (dd:346-348): a dt that
- * is not positive and finite, or a stride that is negative / not finite, would index before path_[0] (undefined behaviour
- * in the reference) and is refused with CCV_MPPI_ERR_INVALID_ARG. */
+ * is negative or not finite, or a stride that is negative / not finite, would index before path_[0] (undefined behaviour
+ * in the reference) and is refused with CCV_MPPI_ERR_INVALID_ARG -- nothing is written to x_ref / y_ref / yaw_ref then, and
+ * the caller must not iterate against the stale window (MPPIBase::run_once() refuses the tick).  dt == 0 is defined in the
+ * reference (stride 0: H copies of the nearest pose, as with v_ref == 0) and admitted. */
 int ccv_mppi_calc_ref_path(const double* path_x, const double* path_y, int32_t n_path, double cur_x, double cur_y,
                            double v_ref, double dt, double resolution, int32_t horizon, double* x_ref, double* y_ref,
                            double* yaw_ref);

@@ -53,6 +53,7 @@ def test_node_closed_loop_matches_oracle(model, kind, over):
     s_o = s_n.copy()
     for it in range(12):
         dt = 0.1 if it % 3 else 0.093          # dt_ is the measured loop period (Q7)
+        s_run = s_n.copy()
         node.set_state(s_n)
         out = node.run_once(dt)
         xr, yr, yaw = O_window(p, (px, py), s_o, dt)
@@ -64,10 +65,45 @@ def test_node_closed_loop_matches_oracle(model, kind, over):
         o.set_nominal(u_n)
         s_n = amd.plant_step(model, s_n, u_n[0], dt)
         s_o = helpers.plant(model, s_o, u_n[0], dt)
-    # optimal path = the optimal controls re-rolled through the plant model (dd:295-312)
+    # optimal path = the optimal controls re-rolled through the plant model from the pose the iteration ran with, with its
+    # dt_ (dd:295-312: predict_NextState(optimal_solution, i) fills state i+1, pose i of the message is state i -- the state
+    # BEFORE step i; sd:328-345 the same with the steered heading; fb:332 has the call commented out, the mirror keeps it)
     op = node.optimal_path()
-    node.set_state(s_n)
     assert op.shape == (p.horizon - 1, 3)
+    s_roll = s_run.copy()
+    want = np.zeros((p.horizon - 1, 3))
+    for i in range(p.horizon - 1):
+        want[i] = s_roll[:3]
+        s_roll = helpers.plant(model, s_roll, u_n[i], dt)
+    np.testing.assert_array_equal(op[0], s_run[:3])
+    np.testing.assert_allclose(op, want, rtol=1e-12, atol=1e-12)   # (the mirror's specified sin / cos vs numpy's: a few ulp)
+    assert np.max(np.abs(op[-1, :2] - op[0, :2])) > 0.1             # (it is a path, not H-1 copies of the pose)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_node_refuses_the_tick_when_the_window_is_refused(fused):
+    """ccv_mppi_calc_ref_path refuses a negative or non-finite loop period and writes no window: the node must not iterate
+    against the stale window and must publish no command (host-prologue paths: fused and stage-wise; the device-prologue
+    path refuses in ccv_mppi_resident_step_enqueue).  dt_ = 0 is defined (stride 0, dd:160-163) and runs."""
+    from ccv_mppi_path_tracker_amd.controller import MPPIError
+    over = {"num_samples": 256, "horizon": 20}
+    px, py = amd.make_path("sinusoid")
+    node = ControllerNode("diff_drive", over, seed=5, fused=fused)
+    node.set_path(px, py)
+    node.set_state([px[3], py[3] + 0.05, 0.1])
+    assert node.run_once(0.1) is not None
+    u_before, win_before = node.optimal_solution(), node.ref_path()
+    for bad in (-0.1, float("inf"), float("nan")):
+        with pytest.raises(MPPIError) as e:
+            node.run_once(bad)
+        assert e.value.code == capi.ERR_INVALID_ARG
+        np.testing.assert_array_equal(node.optimal_solution(), u_before)     # nothing ran, nothing was published
+        np.testing.assert_array_equal(node.ref_path(), win_before)
+    out = node.run_once(0.0)                                                   # two ticks inside one clock tick
+    assert out is not None and np.all(np.isfinite(node.optimal_solution()))
+    win = node.ref_path()
+    assert np.all(win[:, 0] == win[0, 0]) and np.all(win[:, 1] == win[0, 1])   # stride 0: H copies of the nearest pose
+    assert node.run_once(0.1) is not None                                      # and the node carries on
 
 
 def O_window(p, path, state, dt):

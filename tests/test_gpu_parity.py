@@ -678,6 +678,7 @@ def test_full_size_properties(wl):
         assert np.max(np.abs(g.read_costs(first, 192) - c_o) / c_o) < TOL_COST
         xy = g.read_candidates(first, 192, 1)
         np.testing.assert_allclose(xy[..., 0], o.states("x"), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(xy[..., 1], o.states("y"), rtol=1e-12, atol=1e-12)
     # (b) the reduction at full size: weighted mean recomputed on the host from the device's own costs/controls
     c = g.read_costs()
     wts = np.exp(-c / p.lam)

@@ -221,8 +221,9 @@ def test_resident_errors():
 
 
 def test_resident_rejects_bad_dt_before_moving_the_pose():
-    """dt is the stride of the window index (dd:160-163): zero, negative and infinite periods are refused like NaN, on the
-    device path and in ccv_mppi_calc_ref_path alike, and a refused step leaves the pose and the step counter alone."""
+    """dt is the stride of the window index (dd:160-163): negative and infinite periods are refused like NaN, on the
+    device path and in ccv_mppi_calc_ref_path alike, and a refused step leaves the pose and the step counter alone
+    (dt = 0 is defined -- stride 0 -- and admitted by both: test_resident_zero_dt_matches_host_prologue)."""
     p = configs.diff_drive_defaults(256, 30)
     px, py = amd.make_path("sinusoid")
     g = MPPIController(p)
@@ -230,7 +231,7 @@ def test_resident_rejects_bad_dt_before_moving_the_pose():
     g.resident_set_pose([0.3, 0.1, 0.2])
     g.resident_step_enqueue(p.dt, 1, 0, advance=False)
     before = g.resident_read()
-    for bad in (0.0, -0.1, float("inf"), float("-inf"), float("nan"), 1e300):
+    for bad in (-0.1, float("inf"), float("-inf"), float("nan"), 1e300):
         with pytest.raises(MPPIError) as e:
             g.resident_step_enqueue(bad, 1, 1, advance=True)
         assert e.value.code == capi.ERR_INVALID_ARG
@@ -321,3 +322,62 @@ def test_resident_refuses_unbounded_angles_and_commands():
     gs.set_nominal(np.zeros((ps.horizon - 1, ps.udim)))
     gs.resident_step_enqueue(ps.dt, 1, 1, advance=True)
     assert np.all(np.isfinite(gs.get_nominal()))
+
+
+def test_resident_closed_loop_at_full_c2_size():
+    """The device-resident closed loop at the headline size (C2: K = 65 536, T = 50, sinusoid), as bench.py's closed_loop leg
+    runs it: 512 ticks back to back with no host data, the pose fed back every tick.  The robot must track the course
+    (RMS distance to the nearest path pose < 0.1 m -- the reference's own notion of "works", calc_e_rmse.py:30-49) and
+    two runs must end with identical bits everywhere (trace, warm start): the loop has no atomics and no run-to-run freedom."""
+    w = configs.workload("C2")
+    p = w.params
+    ticks = 512
+    need = (ticks + 8) * max(abs(p.u_max[0]), abs(p.u_min[0])) * p.dt + 2.0 * p.horizon * p.v_ref * p.dt
+    px, py = amd.make_path(w.path, p.resolution, length=need)
+    s0 = np.zeros(p.nstate)
+    s0[0], s0[1] = px[0], py[0]
+    runs = []
+    for rep in range(2):
+        g = MPPIController(p)
+        g.resident_set_path(px, py)
+        g.resident_set_pose(s0)
+        for i in range(ticks):
+            g.resident_step_enqueue(p.dt, 42, i, advance=i > 0)
+        g.synchronize()
+        runs.append((g.resident_read_trace(max_rows=ticks), g.get_nominal(), g.resident_read()))
+        g.close()
+    tr = runs[0][0]
+    assert tr.shape == (ticks, 6) and np.all(np.isfinite(tr))
+    d = np.hypot(px[None, :] - tr[:, 0:1], py[None, :] - tr[:, 1:2]).min(axis=1)
+    assert np.sqrt(np.mean(d * d)) < 0.1 and d.max() < 0.3
+    assert np.hypot(np.diff(tr[:, 0]), np.diff(tr[:, 1])).sum() > 0.5 * ticks * p.v_ref * p.dt   # it drove the course
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    np.testing.assert_array_equal(runs[0][2][0], runs[1][2][0])
+    assert runs[0][2][1] == runs[1][2][1] and runs[0][2][5] == runs[1][2][5] == ticks
+
+
+def test_resident_zero_dt_matches_host_prologue():
+    """dt = 0 is defined in the reference (stride 0: the window is H copies of the nearest pose, dd:160-163) and admitted by
+    the host prologue and the resident step alike: same index, same window, same u*, and the plant does not move."""
+    p = configs.diff_drive_defaults(512, 20)
+    px, py = amd.make_path("sinusoid")
+    s0 = np.array([0.7, 0.1, 0.05])
+    g = MPPIController(p)
+    g.resident_set_path(px, py)
+    g.resident_set_pose(s0)
+    g.resident_step_enqueue(p.dt, 3, 0, advance=False)
+    g.resident_step_enqueue(0.0, 3, 1, advance=True)
+    u_res = g.get_nominal()
+    st, idx, xr, yr, _, steps = g.resident_read()
+    np.testing.assert_array_equal(st, s0)                      # dt = 0: the pose stays
+    h = MPPIController(p)
+    i0, wx, wy, wyaw = amd.calc_ref_path(px, py, s0[0], s0[1], p.v_ref, p.dt, p.resolution, p.horizon)
+    h.iterate(s0, p.dt, wx, wy, wyaw[0], 3, 0, want_stats=False)
+    i1, wx, wy, wyaw = amd.calc_ref_path(px, py, s0[0], s0[1], p.v_ref, 0.0, p.resolution, p.horizon)
+    u_host = h.iterate(s0, 0.0, wx, wy, wyaw[0], 3, 1, want_stats=False)
+    assert idx == i1 and steps == 2
+    np.testing.assert_array_equal(xr, wx)
+    np.testing.assert_array_equal(yr, wy)
+    assert np.all(xr == xr[0])
+    np.testing.assert_array_equal(u_res, u_host)

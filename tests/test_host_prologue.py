@@ -39,14 +39,18 @@ def test_ref_window_rejects_bad_arguments():
     with pytest.raises(amd.controller.MPPIError):
         amd.calc_ref_path(px[:0], py[:0], 0.0, 0.0, 1.0, 0.1, 0.1, 10)
     # the window index start + i * v_ref * dt / resolution is the truncation of a double (dd:160-163) and the node takes dt
-    # from its clock (dd:346-348): anything but a positive finite dt and a finite non-negative stride would index before
+    # from its clock (dd:346-348): anything but a finite dt >= 0 and a finite non-negative stride would index before
     # path_[0] (undefined in the reference) and is refused
-    for dt in (0.0, -0.1, float("inf"), float("nan")):
+    for dt in (-0.1, float("inf"), float("nan")):
         with pytest.raises(amd.controller.MPPIError):
             amd.calc_ref_path(px, py, 0.0, 0.0, 1.0, dt, 0.1, 10)
     for v_ref, res in ((-1.0, 0.1), (1.0, -0.1), (float("nan"), 0.1), (1.0, 0.0), (1e308, 1e-308)):
         with pytest.raises(amd.controller.MPPIError):
             amd.calc_ref_path(px, py, 0.0, 0.0, v_ref, 0.1, res, 10)
+    # dt = 0 (two ticks inside one clock tick) is defined in the reference -- stride 0 like v_ref = 0 -- and admitted
+    i0, xr0, yr0, yaw0 = amd.calc_ref_path(px, py, 0.31, 0.0, 1.0, 0.0, 0.1, 10)
+    j0, xq0, yq0, yawq0 = O.calc_ref_path(px, py, 0.31, 0.0, 1.0, 0.0, 0.1, 10)
+    assert i0 == j0 and np.array_equal(xr0, xq0) and np.array_equal(yr0, yq0) and np.all(xr0 == xr0[0])
     idx, xr, yr, yaw = amd.calc_ref_path(px, py, 0.0, 0.0, 0.0, 0.1, 0.1, 10)   # v_ref = 0: stride 0, every point the same
     assert idx == 0 and np.all(xr == px[0])
 
