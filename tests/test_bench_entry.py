@@ -29,9 +29,10 @@ def test_bench_spawns_its_own_ranks_and_relays_their_exit_code():
     if torch.cuda.is_available():
         pytest.skip("the no-GPU exit path needs a box without a GPU")
     r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], timeout=300)
-    # both children ran (each says so), none printed a JSON line, and their exit code (3: no GPU, no CPU fallback) came back
+    # the children ran (the first to give up says why; the parent then stops the other by its PID), none printed a JSON line,
+    # and their exit code (3: no GPU, no CPU fallback) came back
     assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
-    assert r.stderr.count("no GPU visible") == 2, r.stderr[-2000:]
+    assert 1 <= r.stderr.count("no GPU visible") <= 2 and "stopping the other ranks" in r.stderr, r.stderr[-2000:]
     assert r.stdout.strip() == ""
 
 

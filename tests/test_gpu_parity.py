@@ -442,8 +442,10 @@ def test_huge_heading_takes_the_libm_path(model):
 @pytest.mark.parametrize("dt", [0.1, 0.39, 0.4, 1.0])
 def test_diff_drive_turn_per_step_gate(dt):
     """Diff drive advances (sin, cos) of the heading by the step's turn angle w*dt with short polynomials valid for
-    |w| dt <= pi/4 (csrc/fast_trig.h: kernel_sincos_n); the host checks the bound per call and otherwise uses the plain
-    kernel (w_max = 2 rad/s: the switch is at dt = 0.3927).  Either way the oracle's sin(yaw), cos(yaw) are matched."""
+    |w| dt <= pi/4 (csrc/fast_trig.h: kernel_sincos_n); the host checks the bound per call and otherwise launches the same
+    kernel's wide-turn instantiation, which evaluates sin / cos of every heading in full (w_max = 2 rad/s: the switch is at
+    dt = 0.3927; round 2 fell back to the plain kernel there, at twice the time).  Either way the oracle's sin(yaw),
+    cos(yaw) are matched."""
     p = configs.diff_drive_defaults(320, 50).with_(dt=dt)
     path = helpers.oracle_path("sinusoid")
     state = start_state(p, path)
@@ -460,10 +462,10 @@ def test_diff_drive_turn_per_step_gate(dt):
 
 def test_measured_dt_across_the_small_turn_gate(monkeypatch):
     """The node takes dt from its clock (dd:346-348), so one slow tick can cross |w|max * dt = pi/4 (0.3927 s at w_max = 2)
-    and change kernels: the rotation-based production kernel below, the plain kernel with OCML's sincos above
-    (fast_trig_safe, ccv_mppi_capi.hip).  Loop periods drawn around the gate: whatever the host picks must agree with the
-    plain kernel forced (CCV_MPPI_KERNEL=v1) and with the oracle, with no jump at the switch; the warm start carries
-    over from one period to the next as it would in the node."""
+    and change instantiations: the rotation-based production kernel below, its wide-turn form (full-range sin / cos of every
+    heading) above (fast_trig_safe, ccv_mppi_capi.hip).  Loop periods drawn around the gate: whatever the host picks must
+    agree with the plain kernel forced (CCV_MPPI_KERNEL=v1, OCML's sincos) and with the oracle, with no jump at the switch;
+    the warm start carries over from one period to the next as it would in the node."""
     p0 = configs.diff_drive_defaults(640, 50)
     path = helpers.oracle_path("sinusoid")
     state = start_state(p0, path)
