@@ -643,6 +643,8 @@ def main():
                          "iteration_achieved": (B * k_local / iter_avg_s / 1e9) if iter_avg_s > 0 else None,
                          "iteration_frac": (B * k_local / iter_avg_s / 1e9 / HBM_PEAK_GBS) if iter_avg_s > 0 else None},
         }
+        headline = (world == 1 and not args.closed_loop and args.workload == "C2" and args.samples_per_gpu is None
+                    and args.dt is None and args.path is None and not args.no_state_store)
         if world == 1:
             out["roofline"]["device_copy_gbs"] = device_copy_gbs(torch)
             if not args.closed_loop:
@@ -662,9 +664,31 @@ def main():
                     if np.hypot(px_e[-1] - s_e[0], py_e[-1] - s_e[1]) < 1.0:   # end of the course: start over
                         s_e = np.zeros(p.nstate)
                         s_e[0], s_e[1] = px_e[0], py_e[0]
-                out["end_to_end"] = {"blocking_iterate_us_median": 1e6 * float(np.median(lat[20:])),
-                                     "what": "ccv_mppi_calc_ref_path + blocking ccv_mppi_iterate per tick (H2D window, D2H u*, "
-                                             "stream sync), closed loop on the host plant, 200 ticks after 20"}
+                out["end_to_end"] = {"python_binding_us_median": 1e6 * float(np.median(lat[20:])),
+                                     "what": "per tick of a closed loop on the host plant, 200 ticks after 20 -- blocking_iterate: "
+                                             "ONE C call, ccv_mppi_node_run_once() of the ROS-free node mirror = calc_RefPath() on the "
+                                             "host + blocking ccv_mppi_iterate (window in the kernel arguments, u* back through the "
+                                             "pinned result mailbox) + publish_CmdVel/CmdPos: what a node that drops the library in "
+                                             "pays; python_binding: the same two calls through the ctypes wrappers (numpy conversions "
+                                             "included)"}
+                if headline:
+                    from ccv_mppi_path_tracker_amd.node import ControllerNode
+                    node = ControllerNode(p.model, {"num_samples": p.num_samples, "horizon": p.horizon, "v_ref": p.v_ref,
+                                                    "v_max": p.u_max[0], "path_weight": p.path_weight}, device=local_rank)
+                    node.set_path(px_e, py_e)
+                    s_n, lat_n = np.zeros(5), []
+                    s_n[0], s_n[1] = px_e[0], py_e[0]
+                    for i in range(220):
+                        node.set_state(s_n)
+                        t_e = time.perf_counter()
+                        node.run_once(p.dt)
+                        lat_n.append(time.perf_counter() - t_e)
+                        s_n[:p.nstate] = amd.plant_step(p.model, s_n[:p.nstate], node.optimal_solution()[0], p.dt)
+                        if np.hypot(px_e[-1] - s_n[0], py_e[-1] - s_n[1]) < 1.0:
+                            s_n[:] = 0.0
+                            s_n[0], s_n[1] = px_e[0], py_e[0]
+                    node.close()
+                    out["end_to_end"]["blocking_iterate_us_median"] = 1e6 * float(np.median(lat_n[20:]))
         if args.closed_loop:
             tr = ctl.resident_read_trace()
             d = np.hypot(cl_px[None, :] - tr[:, 0:1], cl_py[None, :] - tr[:, 1:2]).min(axis=1)
@@ -672,8 +696,6 @@ def main():
                                   "path_error_rms_m": float(np.sqrt(np.mean(d * d))), "path_error_max_m": float(d.max())}
         if world == 1 and not args.closed_loop and args.workload == "C2" and not args.no_closed_loop_leg:
             out["closed_loop"] = closed_loop_leg(amd, torch, ctl, w, seed)
-        headline = (world == 1 and not args.closed_loop and args.workload == "C2" and args.samples_per_gpu is None
-                    and args.dt is None and args.path is None and not args.no_state_store)
         if headline and not args.no_other_workloads:
             # BASELINE configs[2] and configs[3], measured like the headline (their own handles; C2's is released first)
             ctl.close()

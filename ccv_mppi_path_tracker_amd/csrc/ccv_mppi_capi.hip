@@ -17,11 +17,10 @@
 #include <string>
 #include <vector>
 
+#include "fast_trig.h"
 #include "mppi_kernels.h"
-#include "mppi_rollout_pc.h"
-#include "mppi_rollout_r3.h"
-#include "mppi_rollout_r4.h"
-#include "mppi_rollout_solo.h"
+#include "mppi_launch.h"
+#include "mppi_update.h"
 #include "mppi_resident.h"
 
 using namespace ccv;
@@ -92,6 +91,13 @@ struct ccv_mppi_handle {
     // pinned host staging
     double* h_pin = nullptr;
     size_t pin_doubles = 0;
+    // result mailbox of the blocking calls (FinalizeArgs::mail): pinned host-mapped memory the update kernel writes
+    unsigned long long* h_mail = nullptr;
+    unsigned long long* d_mail = nullptr;   // its device address
+    uint32_t mail_seq = 0;
+    bool want_mail = false;      // the next plain k_finalize launch posts its result (set by the blocking entry points)
+    bool mail_pending = false;   // ... and that launch is in flight: fetch_result() polls the mailbox
+    bool use_mail = true;        // CCV_MPPI_MAILBOX=0: copy + stream synchronisation instead (experiments)
     // stage-wise state
     bool have_controls = false, have_rollout = false, have_weights = false;
     double st_x0[5] = {0, 0, 0, 0, 0};
@@ -241,92 +247,35 @@ void fill_window(const ccv_mppi_handle* h, Window& W, const double* x0, const do
     }
 }
 
-// mode: MODE_FUSED / MODE_ROLLOUT / MODE_COST (mppi_rollout_pc.h)
-template <int MODEL>
+// mode: MODE_FUSED / MODE_ROLLOUT / MODE_COST (mppi_rollout_pc.h).  The kernels live in translation units of their own
+// (mppi_launch.h); a timed fused launch carries its events on the dispatch itself.
 void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const Window& W, int mode) {
+    const int model = h->cfg.model;
+    const bool timed = mode == MODE_FUSED && h->ev_kernel_start;
+    const LaunchAt at{h->stream, timed ? h->ev_kernel_start : nullptr, timed ? h->ev_kernel_stop : nullptr};
     if (h->solo && h->coop && mode == MODE_FUSED) {
         // one wave per 64 samples (mppi_rollout_solo.h): K provides two or more such waves per SIMD
-        const dim3 sgrid((h->K + kPcSamples - 1) / kPcSamples), sblock(kPcSamples);
-        if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
-            if (h->wide_turn) {
-                if (h->ev_kernel_start)
-                    hipExtLaunchKernelGGL((k_rollout_solo<MODEL, MODE_FUSED, true>), sgrid, sblock, 0, h->stream, h->ev_kernel_start,
-                                          h->ev_kernel_stop, 0, A, W);
-                else
-                    hipLaunchKernelGGL((k_rollout_solo<MODEL, MODE_FUSED, true>), sgrid, sblock, 0, h->stream, A, W);
-                return;
-            }
-        }
-        if (h->ev_kernel_start)
-            hipExtLaunchKernelGGL((k_rollout_solo<MODEL, MODE_FUSED>), sgrid, sblock, 0, h->stream, h->ev_kernel_start,
-                                  h->ev_kernel_stop, 0, A, W);
-        else
-            hipLaunchKernelGGL((k_rollout_solo<MODEL, MODE_FUSED>), sgrid, sblock, 0, h->stream, A, W);
+        launch_rollout_solo(model, h->wide_turn, at, A, W);
         return;
     }
-    if constexpr (MODEL != CCV_MPPI_FULL_BODY) {
-    if (h->coop == 3) {
-        // four-wave kernel (mppi_rollout_r4.h)
-        const dim3 cgrid((h->K + kPcSamples - 1) / kPcSamples), cblock(kR4Waves * 64);
-        if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
-            if (mode == MODE_FUSED && h->wide_turn) {
-                if (h->ev_kernel_start)
-                    hipExtLaunchKernelGGL((k_rollout_r4<MODEL, MODE_FUSED, true>), cgrid, cblock, 0, h->stream, h->ev_kernel_start,
-                                          h->ev_kernel_stop, 0, A, W);
-                else
-                    hipLaunchKernelGGL((k_rollout_r4<MODEL, MODE_FUSED, true>), cgrid, cblock, 0, h->stream, A, W);
-                return;
-            }
-        }
-        if (mode == MODE_FUSED && h->ev_kernel_start) {
-            hipExtLaunchKernelGGL((k_rollout_r4<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, h->ev_kernel_start,
-                                  h->ev_kernel_stop, 0, A, W);
-            return;
-        }
-        if (mode == MODE_FUSED) hipLaunchKernelGGL((k_rollout_r4<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, A, W);
-        else if (mode == MODE_ROLLOUT) hipLaunchKernelGGL((k_rollout_r4<MODEL, MODE_ROLLOUT>), cgrid, cblock, 0, h->stream, A, W);
-        else hipLaunchKernelGGL((k_rollout_r4<MODEL, MODE_COST>), cgrid, cblock, 0, h->stream, A, W);
+    if (model != CCV_MPPI_FULL_BODY && h->coop == 3) {   // four-wave kernel (mppi_rollout_r4.h)
+        launch_rollout_r4(model, mode, h->wide_turn, at, A, W);
         return;
     }
-    if (h->coop == 2) {
-        // three-wave kernel (mppi_rollout_r3.h); not built for full body (see ccv_mppi_create)
-        const dim3 cgrid((h->K + kPcSamples - 1) / kPcSamples), cblock(kR3Waves * 64);
-        if (mode == MODE_FUSED && h->ev_kernel_start) {
-            hipExtLaunchKernelGGL((k_rollout_r3<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, h->ev_kernel_start,
-                                  h->ev_kernel_stop, 0, A, W);
-            return;
-        }
-        if (mode == MODE_FUSED) hipLaunchKernelGGL((k_rollout_r3<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, A, W);
-        else if (mode == MODE_ROLLOUT) hipLaunchKernelGGL((k_rollout_r3<MODEL, MODE_ROLLOUT>), cgrid, cblock, 0, h->stream, A, W);
-        else hipLaunchKernelGGL((k_rollout_r3<MODEL, MODE_COST>), cgrid, cblock, 0, h->stream, A, W);
+    if (model != CCV_MPPI_FULL_BODY && h->coop == 2) {   // three-wave kernel (mppi_rollout_r3.h); not built for full body
+        launch_rollout_r3(model, mode, at, A, W);
         return;
     }
-    }
-    if (h->coop) {
-        const dim3 cgrid((h->K + kPcSamples - 1) / kPcSamples), cblock(kPcWaves * 64);
-        if (mode == MODE_FUSED && h->ev_kernel_start) {
-            // timed launch: the events are attached to the dispatch itself (kernel begin / end timestamps)
-            hipExtLaunchKernelGGL((k_rollout_pc<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, h->ev_kernel_start,
-                                  h->ev_kernel_stop, 0, A, W);
-            return;
-        }
-        if (mode == MODE_FUSED) hipLaunchKernelGGL((k_rollout_pc<MODEL, MODE_FUSED>), cgrid, cblock, 0, h->stream, A, W);
-        else if (mode == MODE_ROLLOUT) hipLaunchKernelGGL((k_rollout_pc<MODEL, MODE_ROLLOUT>), cgrid, cblock, 0, h->stream, A, W);
-        else hipLaunchKernelGGL((k_rollout_pc<MODEL, MODE_COST>), cgrid, cblock, 0, h->stream, A, W);
+    if (h->coop) {   // two-wave kernel (mppi_rollout_pc.h)
+        launch_rollout_pc(model, mode, at, A, W);
         return;
     }
-    // experiment path (CCV_MPPI_KERNEL=v1): plain one-sample-per-lane kernel
-    const dim3 grid((h->K + kBlock - 1) / kBlock), block(kBlock);
-    if (mode == MODE_FUSED) {
-        // (timed launch: this path is also the fallback for unbounded headings, so the events must exist here too)
-        if (h->ev_kernel_start) (void)hipEventRecord(h->ev_kernel_start, h->stream);
-        if (h->lds_window) hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_PHILOX, true>), grid, block, 0, h->stream, A, W);
-        else hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_PHILOX, false>), grid, block, 0, h->stream, A, W);
-        if (h->ev_kernel_stop) (void)hipEventRecord(h->ev_kernel_stop, h->stream);
-    } else {
-        if (h->lds_window) hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_BUFFER, true>), grid, block, 0, h->stream, A, W);
-        else hipLaunchKernelGGL((k_rollout_cost<MODEL, SRC_BUFFER, false>), grid, block, 0, h->stream, A, W);
-    }
+    // plain one-sample-per-lane kernel: the path of unbounded headings (fast_trig_safe) and CCV_MPPI_KERNEL=v1
+    // (timed launch: events recorded around it -- the fallback must deliver kernel times too)
+    const LaunchAt plain{h->stream, nullptr, nullptr};
+    if (mode == MODE_FUSED && h->ev_kernel_start) (void)hipEventRecord(h->ev_kernel_start, h->stream);
+    launch_rollout_plain(model, mode == MODE_FUSED, h->lds_window != 0, plain, A, W);
+    if (mode == MODE_FUSED && h->ev_kernel_stop) (void)hipEventRecord(h->ev_kernel_stop, h->stream);
 }
 
 // A deferred ccv_mppi_apply_partials_enqueue is normally consumed by the next fused rollout launch (pc_stage_nominal);
@@ -437,11 +386,7 @@ int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A_in, const Window& W,
     if (mode != MODE_FUSED) {   // the stage-wise kernels read the controls as an array
         if (int rc = materialize_controls(h)) return rc;
     }
-    switch (h->cfg.model) {
-        case CCV_MPPI_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_DIFF_DRIVE>(h, A, W, mode); break;
-        case CCV_MPPI_STEERING_DIFF_DRIVE: launch_rollout_model<CCV_MPPI_STEERING_DIFF_DRIVE>(h, A, W, mode); break;
-        default: launch_rollout_model<CCV_MPPI_FULL_BODY>(h, A, W, mode); break;
-    }
+    launch_rollout_model(h, A, W, mode);
     HIP_TRY(h, hipGetLastError());
     if (mode == MODE_FUSED) h->controls_in_z = h->coop != 0;   // (the plain kernel writes u itself)
     return CCV_MPPI_OK;
@@ -449,12 +394,7 @@ int launch_rollout(ccv_mppi_handle* h, const RolloutArgs& A_in, const Window& W,
 
 int launch_sample(ccv_mppi_handle* h, const RolloutArgs& A) {
     if (int rc = flush_pending(h)) return rc;
-    const dim3 grid((h->K + kBlock - 1) / kBlock, (h->R + 3) / 4), block(kBlock);
-    switch (h->cfg.model) {
-        case CCV_MPPI_DIFF_DRIVE: hipLaunchKernelGGL((k_sample<CCV_MPPI_DIFF_DRIVE>), grid, block, 0, h->stream, A); break;
-        case CCV_MPPI_STEERING_DIFF_DRIVE: hipLaunchKernelGGL((k_sample<CCV_MPPI_STEERING_DIFF_DRIVE>), grid, block, 0, h->stream, A); break;
-        default: hipLaunchKernelGGL((k_sample<CCV_MPPI_FULL_BODY>), grid, block, 0, h->stream, A); break;
-    }
+    launch_sample(h->cfg.model, h->stream, A);
     HIP_TRY(h, hipGetLastError());
     return CCV_MPPI_OK;
 }
@@ -495,6 +435,16 @@ int launch_update(ccv_mppi_handle* h, bool normalise, double* vec_out, bool exch
     F.R = h->R;
     F.nchunks = nparts;
     F.normalise = normalise ? 1 : 0;
+    F.mail = nullptr;
+    F.mail_seq = 0;
+    const bool post = h->want_mail && h->use_mail && normalise && !exchange && !defer && h->d_mail;
+    h->want_mail = false;
+    if (post) {
+        if (++h->mail_seq == 0) h->mail_seq = 1;
+        F.mail = h->d_mail;
+        F.mail_seq = h->mail_seq;
+        h->mail_pending = true;
+    }
     if (exchange) {
         ExchangeArgs X;
         for (int r = 0; r < kMaxRanks; ++r) X.peer[r] = h->box_peer[r];
@@ -607,13 +557,50 @@ int enqueue_iteration(ccv_mppi_handle* h, const double* x0, double dt, const dou
     return CCV_MPPI_OK;
 }
 
+// The blocking calls' result: the update kernel has been told to post u* and the statistics into the pinned mailbox
+// (FinalizeArgs::mail); poll until every packet carries this call's sequence number.  Costs the PCIe write latency after the
+// kernel's last store instead of two copy-engine transfers and a stream synchronisation (C2: 72 -> ~50 us per blocking
+// iteration; the reference defaults, K = 1 000, H = 15: 34 -> ~25 us).  A kernel that never posts (a fault, a lost device)
+// is found by the stream query / synchronisation the poll falls back to, so the call returns an error instead of spinning.
+int wait_mail(ccv_mppi_handle* h, const size_t n_slots) {
+    const uint32_t seq = h->mail_seq;
+    volatile unsigned long long* m = h->h_mail;
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t next = 0;
+    bool synced = false;
+    for (unsigned spin = 0;; ++spin) {
+        while (next < n_slots && (uint32_t)m[2 * next] == seq && (uint32_t)m[2 * next + 1] == seq) ++next;
+        if (next == n_slots) return CCV_MPPI_OK;
+        if (synced) return fail(h, CCV_MPPI_ERR_HIP, "the update kernel finished without posting its result");
+        asm volatile("" ::: "memory");
+        if ((spin & 1023u) == 1023u) {
+            // a long kernel (K in the millions) or a stuck one: stop burning a core after a millisecond and let the runtime wait
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > 1.0e-3) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                synced = true;   // (one more sweep: everything the kernel posted is visible now)
+            }
+        }
+    }
+}
+
 int fetch_result(ccv_mppi_handle* h, double* u_opt_out, ccv_mppi_stats* stats) {
     if (int rc = flush_pending(h)) return rc;
-    // one D2H of [u* | stats] through pinned memory, then a stream sync
     const size_t n = (size_t)h->R;
-    HIP_TRY(h, hipMemcpyAsync(h->h_pin, h->d_nominal, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->h_pin + n, h->d_stats, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->mail_pending) {
+        h->mail_pending = false;
+        if (int rc = wait_mail(h, n + (stats ? 4 : 0))) return rc;
+        for (size_t i = 0; i < n + (stats ? 4u : 0u); ++i) {
+            const unsigned long long hi = h->h_mail[2 * i], lo = h->h_mail[2 * i + 1];
+            const unsigned long long bits = (hi & 0xFFFFFFFF00000000ull) | (lo >> 32);
+            std::memcpy(&h->h_pin[i], &bits, sizeof(double));
+        }
+    } else {
+        // one D2H of [u* | stats] through pinned memory, then a stream sync
+        HIP_TRY(h, hipMemcpyAsync(h->h_pin, h->d_nominal, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_pin + n, h->d_stats, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     int nonfinite = 0;
     for (size_t i = 0; i < n; ++i) {
         if (!std::isfinite(h->h_pin[i])) nonfinite = 1;
@@ -824,6 +811,15 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     h->pin_doubles = (size_t)h->R + 16;
     if ((e = hipHostMalloc(&h->h_pin, h->pin_doubles * sizeof(double), hipHostMallocDefault)) != hipSuccess)
         return bail(CCV_MPPI_ERR_ALLOC, "hipHostMalloc", e);
+    {
+        const size_t mail_bytes = ((size_t)h->R + 4) * 2 * sizeof(unsigned long long);
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->h_mail), mail_bytes, hipHostMallocMapped)) != hipSuccess)
+            return bail(CCV_MPPI_ERR_ALLOC, "hipHostMalloc(mailbox)", e);
+        std::memset(h->h_mail, 0, mail_bytes);   // (sequence numbers start at 1: nothing in a fresh box is taken for a packet)
+        if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mail), h->h_mail, 0)) != hipSuccess)
+            return bail(CCV_MPPI_ERR_HIP, "hipHostGetDevicePointer(mailbox)", e);
+        if (const char* mv = std::getenv("CCV_MPPI_MAILBOX")) h->use_mail = std::strcmp(mv, "0") != 0;
+    }
     if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipDeviceSynchronize", e);
     *out = h;
     return CCV_MPPI_OK;
@@ -846,6 +842,7 @@ int ccv_mppi_destroy(ccv_mppi_handle* h) {
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->h_mail) (void)hipHostFree(h->h_mail);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (prev >= 0 && prev != h->cfg.device) (void)hipSetDevice(prev);
     delete h;
@@ -862,17 +859,6 @@ int ccv_mppi_set_stream(ccv_mppi_handle* h, void* hip_stream) {
 }
 
 #if defined(CCV_STAMP)
-extern "C" int ccv_mppi_debug_occupancy(int* out3) {
-    hipFuncAttributes fa;
-    int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout_pc<CCV_MPPI_DIFF_DRIVE, MODE_FUSED>, kPcWaves * 64, 0);
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_rollout_pc<CCV_MPPI_DIFF_DRIVE, MODE_FUSED>));
-    out3[0] = nb;
-    out3[1] = fa.numRegs;
-    out3[2] = (int)fa.sharedSizeBytes;
-    out3[3] = (int)fa.localSizeBytes;
-    return 0;
-}
 extern "C" int ccv_mppi_debug_stamps(ccv_mppi_handle* h, unsigned long long* out32) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(out32, h->d_dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -919,7 +905,9 @@ int ccv_mppi_iterate(ccv_mppi_handle* h, const double* x0, double dt, const doub
                      double yaw_ref0, uint64_t seed, uint64_t iter, double* u_opt_out, ccv_mppi_stats* stats) {
     int rc = check_iter_args(h, x0, dt, x_ref, y_ref);
     if (rc) return rc;
+    h->want_mail = !(stats && h->timing);   // (a timed call synchronises for its events anyway)
     rc = enqueue_iteration(h, x0, dt, x_ref, y_ref, yaw_ref0, seed, iter, true, nullptr);
+    h->want_mail = false;
     if (rc) return rc;
     return fetch_result(h, u_opt_out, stats);
 }
@@ -1284,7 +1272,9 @@ int ccv_mppi_sample(ccv_mppi_handle* h, uint64_t seed, uint64_t iter) {
     fill_args(h, A, zero, 0.1, 0.0, seed, iter);
     int rc = launch_sample(h, A);
     if (rc) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // (no host wait: the stage-wise calls hand nothing back to the host before ccv_mppi_update -- sampling(),
+    //  predict_States() and calc_Weights() are void in the reference -- so they only enqueue; the stream keeps their order,
+    //  ccv_mppi_update and every read-back wait for what they return)
     for (int d = 0; d < h->udim; ++d) h->inj_absmax[d] = std::fmax(std::fabs(h->cfg.u_min[d]), std::fabs(h->cfg.u_max[d]));
     h->controls_in_z = false;
     h->have_controls = true;
@@ -1324,7 +1314,6 @@ int ccv_mppi_rollout(ccv_mppi_handle* h, const double* x0, double dt) {
     A.do_cost = 0;
     int rc = launch_rollout(h, A, W, MODE_ROLLOUT);
     if (rc) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(h->st_x0, A.x0, sizeof(h->st_x0));
     h->st_dt = dt;
     h->have_rollout = true;
@@ -1348,7 +1337,6 @@ int ccv_mppi_weights(ccv_mppi_handle* h, const double* x_ref, const double* y_re
     // sum of weights (calc_Weights normalises, dd:222) without touching u*
     rc = launch_update(h, false, nullptr);
     if (rc) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_weights = true;
     return CCV_MPPI_OK;
 }
@@ -1356,7 +1344,9 @@ int ccv_mppi_weights(ccv_mppi_handle* h, const double* x_ref, const double* y_re
 int ccv_mppi_update(ccv_mppi_handle* h, double* u_opt_out, ccv_mppi_stats* stats) {
     if (!h) return CCV_MPPI_ERR_INVALID_ARG;
     if (!h->have_weights) return fail(h, CCV_MPPI_ERR_STATE, "ccv_mppi_update before ccv_mppi_weights");
+    h->want_mail = !(stats && h->timing);
     int rc = launch_update(h, true, nullptr);
+    h->want_mail = false;
     if (rc) return rc;
     return fetch_result(h, u_opt_out, stats);
 }

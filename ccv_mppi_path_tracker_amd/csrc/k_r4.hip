@@ -1,0 +1,26 @@
+// translation unit: the four-wave rollout kernel (mppi_rollout_r4.h), diff drive and steering
+#include "mppi_launch.h"
+#include "mppi_rollout_r4.h"
+
+namespace ccv {
+
+template <int MODEL>
+static void launch_r4_model(int mode, bool wide, const LaunchAt& at, const RolloutArgs& A, const Window& W) {
+    const dim3 grid = blocks_of_64(A), block(kR4Waves * 64);
+    if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE) {
+        if (mode == MODE_FUSED && wide) {
+            launch_at(k_rollout_r4<MODEL, MODE_FUSED, true>, grid, block, at, A, W);
+            return;
+        }
+    }
+    if (mode == MODE_FUSED) launch_at(k_rollout_r4<MODEL, MODE_FUSED>, grid, block, at, A, W);
+    else if (mode == MODE_ROLLOUT) launch_at(k_rollout_r4<MODEL, MODE_ROLLOUT>, grid, block, at, A, W);
+    else launch_at(k_rollout_r4<MODEL, MODE_COST>, grid, block, at, A, W);
+}
+
+void launch_rollout_r4(int model, int mode, bool wide, const LaunchAt& at, const RolloutArgs& A, const Window& W) {
+    if (model == CCV_MPPI_DIFF_DRIVE) launch_r4_model<CCV_MPPI_DIFF_DRIVE>(mode, wide, at, A, W);
+    else launch_r4_model<CCV_MPPI_STEERING_DIFF_DRIVE>(mode, false, at, A, W);
+}
+
+}  // namespace ccv

@@ -15,7 +15,7 @@
 // differ from libm's in the last place (only fb:408 reads it).
 #pragma once
 #include "fast_trig.h"
-#include "mppi_kernels.h"
+#include "mppi_update.h"
 
 namespace ccv {
 

@@ -25,12 +25,6 @@
 namespace ccv {
 
 constexpr int kPcWaves = 2;
-constexpr int kPcSamples = 64;
-
-enum : int { MODE_FUSED = 0, MODE_ROLLOUT = 1, MODE_COST = 2 };
-//   MODE_FUSED    device Philox noise, controls + states stored, cost + weight   (ccv_mppi_iterate*)
-//   MODE_ROLLOUT  controls read from HBM, states stored, no cost                  (ccv_mppi_rollout)
-//   MODE_COST     controls read from HBM, nothing stored but cost + weight        (ccv_mppi_weights)
 
 #if defined(CCV_STAMP)
 struct PcStamps { unsigned long long acc[8]; unsigned long long last; };
@@ -43,7 +37,7 @@ struct PcStamps { unsigned long long acc[8]; unsigned long long last; };
         (st).acc[slot] += now__ - (st).last;                                                 \
         (st).last = now__;                                                                   \
     } while (0)
-__device__ PcStamps g_stamps_dummy;
+static __device__ PcStamps g_stamps_dummy;
 #else
 #define CCV_STAMP_AT(st, slot) do {} while (0)
 #endif

@@ -18,7 +18,10 @@
  *   - an opaque handle owns all device memory, allocated once in ccv_mppi_create() (the reference allocates
  *     everything once in the constructor, src/diff_drive_mppi.cpp:36-46) and never resized;
  *   - the caller owns all host arrays; pointers are host pointers unless a parameter name starts with `dev_`;
- *   - one handle = one caller thread; calls are blocking unless named *_async / *_enqueue;
+ *   - one handle = one caller thread; a call that hands data back to the host (ccv_mppi_iterate, ccv_mppi_update, the
+ *     read-backs, ccv_mppi_get_nominal) returns when that data is complete; calls named *_enqueue and the stage-wise calls
+ *     that return nothing to the host (ccv_mppi_sample, ccv_mppi_rollout, ccv_mppi_weights -- void methods in the
+ *     reference) only enqueue work on the handle's stream, which keeps the order; ccv_mppi_synchronize waits for all of it;
  *   - all floating point data is IEEE double (the reference computes in double throughout);
  *   - there is NO CPU fallback: without a usable HIP device every call fails with CCV_MPPI_ERR_NO_DEVICE.
  */

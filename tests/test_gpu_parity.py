@@ -178,6 +178,38 @@ def test_fused_equals_stagewise_bitwise(name):
     assert st_a.sum_w == st_b.sum_w
 
 
+@pytest.mark.parametrize("name", ["dd_K256_H50_sinusoid_C2", "fb_K128_H80_dkan_C4"])
+def test_blocking_result_mailbox_equals_copy_and_synchronise(monkeypatch, name):
+    """The blocking calls (ccv_mppi_iterate, ccv_mppi_update) get u* and the statistics from a mailbox in pinned host memory
+    that the update kernel writes itself (self-validating packets, polled by the host) instead of two device-to-host copies
+    and a stream synchronisation (CCV_MPPI_MAILBOX=0): the same bits, call after call, with and without a statistics
+    pointer, fused and stage-wise, and ccv_mppi_get_nominal (a copy) agrees with what the mailbox delivered."""
+    p, kind = CASES[name]
+    path = helpers.oracle_path(kind)
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    a = MPPIController(p)
+    monkeypatch.setenv("CCV_MPPI_MAILBOX", "0")
+    b = MPPIController(p)
+    for it in range(6):
+        if it % 2:
+            u_a, u_b = (g.iterate(state, p.dt, xr, yr, yaw[0], 3, it, want_stats=False) for g in (a, b))
+        else:
+            (u_a, st_a), (u_b, st_b) = (g.iterate(state, p.dt, xr, yr, yaw[0], 3, it) for g in (a, b))
+            assert (st_a.sum_w, st_a.min_cost, st_a.max_cost, st_a.n_zero_weight, st_a.nonfinite) == \
+                   (st_b.sum_w, st_b.min_cost, st_b.max_cost, st_b.n_zero_weight, st_b.nonfinite)
+            assert st_a.min_cost == a.read_costs().min() and st_a.max_cost == a.read_costs().max()
+        np.testing.assert_array_equal(u_a, u_b)
+        np.testing.assert_array_equal(u_a, a.get_nominal())
+    for g in (a, b):
+        g.sampling(3, 9)
+        g.predict_States(state, p.dt)
+        g.calc_Weights(xr, yr, yaw[0])
+    (u_a, st_a), (u_b, st_b) = (g.determine_OptimalSolution(want_stats=True) for g in (a, b))
+    np.testing.assert_array_equal(u_a, u_b)
+    assert st_a.sum_w == st_b.sum_w and np.all(np.isfinite(u_a))
+
+
 @pytest.mark.parametrize("name", ["dd_K256_H50_sinusoid_C2", "sd_K256_H50_sinusoid_C3", "fb_K128_H80_dkan_C4"])
 def test_kernel_variants_agree(monkeypatch, name):
     """The production kernels (two or four waves share 64 samples) against the plain one-sample-per-lane variants kept for
