@@ -52,7 +52,7 @@ struct ccv_mppi_handle {
     double* d_vec = nullptr;
     double* d_stats = nullptr;
     double* d_cmin = nullptr;
-    unsigned long long* d_dbg = nullptr;   // CCV_STAMP diagnostic builds
+    unsigned long long* d_dbg = nullptr;   // -DCCV_DIAG builds only (mppi_diag.h): the kernels' stamp buffer
     // device-resident closed loop (mppi_resident.h)
     ResidentFrame* d_frame = nullptr;
     double* d_path = nullptr;    // [2][n_path]: x then y
@@ -741,8 +741,11 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     }
     // wave priorities (pc_rotate_priority): measured -4 us on the three-wave kernel (C2), -3 % on the two-wave one (C4), and
     // with four levels -5 us on the four-wave kernel (43.4 -> 38.3 us at C2)
-    h->prio_rotate = h->coop == 3 ? 2 : h->coop ? 1 : 0;
-    if (const char* pv = std::getenv("CCV_MPPI_PRIO")) h->prio_rotate = std::atoi(pv) != 0 ? h->prio_rotate : 0;
+    h->prio_rotate = h->coop == 3 ? 5 : h->coop ? 1 : 0;
+    if (const char* pv = std::getenv("CCV_MPPI_PRIO")) {
+        const int v = std::atoi(pv);
+        h->prio_rotate = v == 0 ? 0 : (v >= 2 && v <= 5 && h->coop == 3) ? v : h->prio_rotate;   // (2 .. 5: r4_rotate_priority's schedules)
+    }
 
     // Exact window pruning in the distance loop (pc_prune_window).  Measured on one box, kernel us off -> on: diff drive
     // K = 65 536 49.0 -> 42.7, steering 61.7 -> 57.3 (three-wave kernels).  CCV_MPPI_PRUNE=0/1 forces it (experiments;
@@ -802,8 +805,12 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
         if ((e = hipMalloc(a.p, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
         if ((e = hipMemset(*a.p, 0, a.n * sizeof(double))) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipMemset", e);
     }
-#if defined(CCV_STAMP)
-    if ((e = hipMalloc(&h->d_dbg, (64 + 6 * 4096) * sizeof(unsigned long long))) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
+#if defined(CCV_DIAG)
+    {
+        const size_t dbg_bytes = (size_t)(kDiagHeader + kDiagSlots * kDiagBlocks) * sizeof(unsigned long long);
+        if ((e = hipMalloc(&h->d_dbg, dbg_bytes)) != hipSuccess) return bail(CCV_MPPI_ERR_ALLOC, "hipMalloc", e);
+        if ((e = hipMemset(h->d_dbg, 0, dbg_bytes)) != hipSuccess) return bail(CCV_MPPI_ERR_HIP, "hipMemset", e);
+    }
 #endif
     if (const char* tv = std::getenv("CCV_MPPI_THROTTLE")) h->throttle = std::strcmp(tv, "0") != 0;
     for (hipEvent_t& te : h->throttle_ev)
@@ -858,15 +865,13 @@ int ccv_mppi_set_stream(ccv_mppi_handle* h, void* hip_stream) {
     return CCV_MPPI_OK;
 }
 
-#if defined(CCV_STAMP)
-extern "C" int ccv_mppi_debug_stamps(ccv_mppi_handle* h, unsigned long long* out32) {
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(out32, h->d_dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return CCV_MPPI_OK;
-}
+
+#if defined(CCV_DIAG)
+// diagnostic builds: the stamps of the first `nblocks` workgroups of the last launch, kDiagSlots values each (mppi_diag.h)
 extern "C" int ccv_mppi_debug_blocks(ccv_mppi_handle* h, unsigned long long* out, int nblocks) {
+    if (!h || !out || nblocks < 0 || nblocks > kDiagBlocks) return CCV_MPPI_ERR_INVALID_ARG;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(out, h->d_dbg + 64, (size_t)nblocks * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out, h->d_dbg + kDiagHeader, (size_t)nblocks * kDiagSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CCV_MPPI_OK;
 }
 #endif

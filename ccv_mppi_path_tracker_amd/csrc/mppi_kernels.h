@@ -29,6 +29,13 @@
 #include "../../include/ccv_mppi.h"
 #include "noise_spec.h"
 
+#if defined(CCV_DIAG)
+#include "mppi_diag.h"   // in-kernel time stamps of the diagnostic builds (tools/ablate.py, tools/stamps_r4.py)
+#else
+#define CCV_DIAG_STAMP(A, slot) do {} while (0)   // a product build contains nothing of the diagnostics
+#define CCV_DIAG_STAMP_VALUE(A, slot, value) do {} while (0)
+#endif
+
 namespace ccv {
 
 constexpr int kMaxH = CCV_MPPI_MAX_HORIZON;
@@ -97,8 +104,23 @@ struct RolloutArgs {
     double* nominal_w;
     double* stats_w;
     const ResidentFrame* frame;   // device-resident pose and window (null: x0, yaw_ref0 and the Window argument)
-    unsigned long long* dbg;   // diagnostic builds only (CCV_STAMP): per-phase cycle sums
+    unsigned long long* dbg;   // diagnostic builds only (-DCCV_DIAG, mppi_diag.h): the stamp buffer; null otherwise
 };
+
+// Every 64-byte line of the RolloutArgs block of the kernel arguments, requested at once.  The host wrote the block into
+// device memory a moment ago and every launch starts with an invalidated scalar cache, so the first use of a field is a miss
+// all the way to HBM (0.4 us on an idle chip, about 1 us on a busy one) -- and the compiler loads the fields where they are
+// first needed: three to four of those latencies in a row before a wave has done anything (entry -> first arguments ->
+// pointers -> loop bounds).  One dword of each line, all in flight together, then one wait: the lines are in the scalar
+// cache, every later load of a field hits.
+__device__ __forceinline__ void touch_rollout_args() {
+    typedef const uint32_t __attribute__((address_space(4))) * ConstArgWords;
+    ConstArgWords ka = (ConstArgWords)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t t = 0;
+#pragma unroll
+    for (int off = 0; off < (int)sizeof(RolloutArgs); off += 64) t |= ka[off / 4];
+    asm volatile("" ::"s"(t));
+}
 
 // the kernel arguments with the resident pose substituted (wave-uniform scalar loads)
 __device__ __forceinline__ RolloutArgs with_resident_pose(const RolloutArgs& Ak) {
@@ -232,12 +254,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, co
             px[tt] = x - A.x0[0];
             py[tt] = y - A.x0[1];
             if (t < H) {
-#if !defined(CCV_ABL_NO_STORE)
                 if (A.store_xy && live) {
                     A.xs[(size_t)t * pitch + k] = x;
                     A.ys[(size_t)t * pitch + k] = y;
                 }
-#endif
                 if (t < H - 1) {
                     double u[UD];
                     static_for<UD>([&](auto D) {
@@ -246,19 +266,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, co
                         const size_t row = (size_t)(t * UD + d);
                         if constexpr (SRC == SRC_PHILOX) {
                             if constexpr ((nloc & 3) == 0) {
-#if defined(CCV_ABL_NO_NOISE)
-                                zq[0] = zq[1] = zq[2] = zq[3] = (float)kg * 1e-6f;
-#else
                                 const Philox4 r = philox4x32_10(kg, (uint32_t)((t0 * UD + nloc) >> 2), A.iter_lo,
                                                                 A.iter_hi, A.seed_lo, A.seed_hi);
-#if defined(CCV_ABL_NO_BM)
-                                zq[0] = (float)r.x * 1e-10f; zq[1] = (float)r.y * 1e-10f;
-                                zq[2] = (float)r.z * 1e-10f; zq[3] = (float)r.w * 1e-10f;
-#else
                                 box_muller_f32(r.x, r.y, zq[0], zq[1]);
                                 box_muller_f32(r.z, r.w, zq[2], zq[3]);
-#endif
-#endif
                             }
                             // libstdc++ normal_distribution: ret * stddev + mean (dd:96-97), then clamp (dd:98-99)
                             double v = (double)zq[nloc & 3] * A.sigma + A.nominal[row];
@@ -267,9 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, co
                                 if (A.steer_off) v = 0.0;  // fb:517
                             }
                             u[d] = v;
-#if !defined(CCV_ABL_NO_STORE)
                             if (A.store_u && live) A.u[row * pitch + k] = v;
-#endif
                         } else {
                             u[d] = A.u[row * pitch + kk];
                         }
@@ -298,11 +307,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, co
                     double hd = yaw;
                     if constexpr (MODEL != CCV_MPPI_DIFF_DRIVE) hd = yaw + u[2];
                     double sn, cs;
-#if defined(CCV_ABL_NO_SINCOS)
-                    sn = hd * 0.5; cs = 1.0 - hd * 0.25;
-#else
                     sincos(hd, &sn, &cs);
-#endif
                     if constexpr (MODEL == CCV_MPPI_FULL_BODY) {
                         if (A.do_cost) {
                             double sd_, cd_, sr_, cr_;
@@ -336,11 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_cost(const RolloutArgs A, co
         if (A.do_cost) {
             // states that reach the path cost: all H for dd/sd (dd:199), the first H-2 for fb (fb:409)
             const int nstates = (MODEL == CCV_MPPI_FULL_BODY) ? H - 2 : H;
-#if defined(CCV_ABL_NO_DIST)
-            const int nv = 0;
-#else
             const int nv = min(kTU, nstates - t0);
-#endif
             if (nv > 0) {
                 double m[kTU];
 #pragma unroll

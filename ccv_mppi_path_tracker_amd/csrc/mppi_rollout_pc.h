@@ -26,21 +26,6 @@ namespace ccv {
 
 constexpr int kPcWaves = 2;
 
-#if defined(CCV_STAMP)
-struct PcStamps { unsigned long long acc[8]; unsigned long long last; };
-#define CCV_STAMP_AT(st, slot)                                                              \
-    do {                                                                                     \
-        unsigned long long now__;                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now__)::"memory");        \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        (st).acc[slot] += now__ - (st).last;                                                 \
-        (st).last = now__;                                                                   \
-    } while (0)
-static __device__ PcStamps g_stamps_dummy;
-#else
-#define CCV_STAMP_AT(st, slot) do {} while (0)
-#endif
 
 // element d of a 5-entry kernel-argument array for a compile-time d
 template <int D>
@@ -59,10 +44,9 @@ constexpr int kPcStateWords = MODEL == CCV_MPPI_FULL_BODY ? 12 : (MODEL == CCV_M
 
 template <int MODEL>
 struct PcShared {
-    // kStage: the producer hands its controls and states to a store wave through LDS instead of storing them itself
-    // (mppi_rollout_r3.h); here it stores them to HBM directly
+    // kStage: the producer hands its normals (sh.zs) and states to a store wave through LDS instead of storing them itself
+    // (mppi_rollout_r3.h, mppi_rollout_r4.h); here it stores them to HBM directly
     static constexpr bool kStage = false;
-    static constexpr bool kStageNoise = false;   // (with kStage) the fp32 normals are staged instead of the fp64 controls
     static constexpr int kPBuf = 2;              // buffers of p: the block being produced and the one being consumed
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
     double c[kMaxH + 4];
@@ -129,11 +113,7 @@ __device__ __forceinline__ double pc_control_from_normal(const RolloutArgs& A, c
 // The candidate states x, y are written once and not read again by this kernel: streaming (non-temporal) stores keep
 // them from displacing the controls, which the epilogue re-reads, from L2 and from piling up as dirty lines that the
 // end-of-kernel write-back has to drain.
-#if defined(CCV_EXP_PLAIN_STATE_STORE)
-#define CCV_STATE_STORE(ptr, val) (*(ptr) = (val))
-#else
 #define CCV_STATE_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#endif
 
 // Stores with a scalar base: address = (uniform 64-bit row pointer) + (32-bit lane offset).  The compiler hoists the
 // zero-extension of the lane offset out of the loop and then adds 64-bit vector addresses (one v_lshl_add_u64 per store,
@@ -173,6 +153,21 @@ __device__ __forceinline__ void pc_rotate_priority(const RolloutArgs& A, const i
         else __builtin_amdgcn_s_setprio(0);
     } else {
         pc_set_priority((rank + s) & 3);
+    }
+}
+
+// four-wave kernel: the level from the workgroup's dispatch rank, the time block and the wave's role.  prio_rotate 5 (the
+// default): (role - rank - b) mod 4; 2: (rank + b + role) mod 4, round 2's schedule; 3, 4: the other two sign combinations
+// (CCV_MPPI_PRIO=2..5; measured kernel times at C2 on one box, with the prologue's rank priorities: 5: 32.2 us, 2: 32.5,
+// 4: about 2's, 3: +1.0)
+__device__ __forceinline__ void r4_rotate_priority(const RolloutArgs& A, const int b, const int role) {
+    if (!A.prio_rotate) return;
+    const int rank = (int)blockIdx.x / A.cu_count;
+    switch (A.prio_rotate) {
+        case 2: pc_set_priority((rank + role + b) & 3); break;
+        case 3: pc_set_priority((rank + role - b) & 3); break;
+        case 4: pc_set_priority((role - rank + b) & 3); break;
+        default: pc_set_priority((role - rank - b) & 3); break;
     }
 }
 
@@ -226,12 +221,10 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
         }
         if (FULL || t < H) {
             if constexpr (MODE != MODE_COST && !SH::kStage) {
-#if !defined(CCV_ABL_NO_STORE)
                 if (A.store_xy && live) {
                     CCV_STATE_STORE(&A.xs[(size_t)t * pitch + k], S.x);
                     CCV_STATE_STORE(&A.ys[(size_t)t * pitch + k], S.y);
                 }
-#endif
             }
             if (FULL || t < H - 1) {
                 double u[UD];
@@ -243,13 +236,9 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
                         if constexpr ((nloc & 3) == 0) {
                             // warm start u*[n .. n+3]: wave-uniform load, in flight while the Philox rounds run
                             nom = *reinterpret_cast<const double4*>(&sh.nom[n]);
-#if defined(CCV_ABL_NO_NOISE)
-                            zq[0] = zq[1] = zq[2] = zq[3] = (float)(kg & 1023u) * 1e-3f - 0.5f;
-#else
                             const Philox4 r = philox4x32_10(kg, (uint32_t)(n >> 2), A.iter_lo, A.iter_hi, A.seed_lo, A.seed_hi);
                             box_muller_f32(r.x, r.y, zq[0], zq[1]);
                             box_muller_f32(r.z, r.w, zq[2], zq[3]);
-#endif
                         }
                         constexpr int q = nloc & 3;
                         const double mean = q == 0 ? nom.x : q == 1 ? nom.y : q == 2 ? nom.z : nom.w;
@@ -261,12 +250,9 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
                         }
                         u[d] = v;
                         if constexpr (SH::kStage) {
-                            if constexpr (SH::kStageNoise) sh.zs[b & 1][nloc][lane] = zq[q];
-                            else sh.us[b & 1][nloc][lane] = v;
+                            sh.zs[b & 1][nloc][lane] = zq[q];
                         } else {
-#if !defined(CCV_ABL_NO_STORE)
                             if (live) A.z[(size_t)n * pitch + k] = zq[q];
-#endif
                         }
                     } else {
                         u[d] = A.u[(size_t)n * pitch + kk];
@@ -297,11 +283,7 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
                 double hd = S.yaw;
                 if constexpr (MODEL != CCV_MPPI_DIFF_DRIVE) hd = S.yaw + u[2];
                 double sn, cs;
-#if defined(CCV_ABL_NO_SINCOS)
-                sn = hd * 0.5; cs = 1.0 - hd * 0.25;
-#else
                 fast_sincos(hd, sn, cs);
-#endif
                 if constexpr (FB && COST) {
                     double sd_, cd_, sr_, cr_, sp_, cp_;
                     fast_sincos(u[2], sd_, cd_);
@@ -337,10 +319,6 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
 template <int MODEL, int C0, int CN>
 __device__ __forceinline__ void pc_block_normals(const RolloutArgs& A, const int b, const uint32_t kg, float (&z)[4 * CN]) {
     constexpr int UD = udim_of(MODEL);
-#if defined(CCV_ABL_NO_NOISE)
-#pragma unroll
-    for (int i = 0; i < 4 * CN; ++i) z[i] = (float)(kg & 1023u) * 1e-3f - 0.5f;
-#else
     uint32_t c0[CN], c1[CN], c2[CN], c3[CN];
 #pragma unroll
     for (int i = 0; i < CN; ++i) {
@@ -365,7 +343,6 @@ __device__ __forceinline__ void pc_block_normals(const RolloutArgs& A, const int
         z[2 * i] = z0[i];
         z[2 * i + 1] = z1[i];
     }
-#endif
 }
 
 // Full body, two-wave kernel: the producer (10 Philox calls, 20 Box-Muller pairs, 32 sin/cos per block) takes 1.5x as
@@ -393,12 +370,8 @@ __device__ __forceinline__ void pc_noise_ahead(const RolloutArgs& A, float (*slo
 template <int MODEL, int MODE, class SH, bool ZLDS = false, bool FASTCLAMP = false, bool WIDE = false>
 __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh, PcState<MODEL>& S, double& cost,
                                                    const int b, const int lane, const int k, const int kk, const bool live,
-                                                   const uint32_t kg
-#if defined(CCV_STAMP)
-                                                   , PcStamps& ST
-#endif
-                                                   , const float (*ahead)[kPcSamples] = nullptr   // pc_noise_ahead's slot
-                                                   ) {
+                                                   const uint32_t kg,
+                                                   const float (*ahead)[kPcSamples] = nullptr) {   // pc_noise_ahead's slot
     constexpr int UD = udim_of(MODEL);
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     constexpr bool COST = MODE != MODE_ROLLOUT;
@@ -440,15 +413,11 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
                 }
                 u[tt][d] = v;
                 if constexpr (SH::kStage) {
-                    if constexpr (ZLDS) {
-                    } else if constexpr (SH::kStageNoise) sh.zs[b & 1][nloc][lane] = z[i];
-                    else sh.us[b & 1][nloc][lane] = v;
+                    if constexpr (!ZLDS) sh.zs[b & 1][nloc][lane] = z[i];   // (ZLDS: the noise wave has put it there)
                 } else {
-#if !defined(CCV_ABL_NO_STORE)
                     // no `live` predicate: rows are padded to a multiple of 64 samples (pitch), lanes past K write their
                     // padding slot -- a branch per store would cut this block into pieces the scheduler cannot interleave
                     A.z[(size_t)(t0 * UD + nloc) * pitch + k] = z[i];
-#endif
                 }
             });
         };
@@ -470,7 +439,6 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
 #pragma unroll
             for (int d = 0; d < UD; ++d) u[tt][d] = A.u[(size_t)((t0 + tt) * UD + d) * pitch + kk];
     }
-    CCV_STAMP_AT(ST, 0);
     // ---- 2. heading (roll, pitch) recurrences: yaw[t+1] = yaw[t] + w[t]*dt (dd:108, fb:449-451)
     double yawv[kTU + 1], rollv[FB ? kTU + 1 : 1], pitchv[FB ? kTU + 1 : 1];
     yawv[0] = S.yaw;
@@ -494,14 +462,9 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
         hd[tt] = yawv[tt];
         if constexpr (MODEL != CCV_MPPI_DIFF_DRIVE) hd[tt] = yawv[tt] + u[tt][2];
     }
-    CCV_STAMP_AT(ST, 1);
     // ---- 3. sin/cos of the 8 headings
     double sn[kTU], cs[kTU];
     double fb_sd[FB ? kTU : 1], fb_cd[FB ? kTU : 1], fb_sr[FB ? kTU : 1], fb_cr[FB ? kTU : 1], fb_cp[FB ? kTU : 1];   // full body: direction, roll, pitch
-#if defined(CCV_ABL_NO_SINCOS)
-#pragma unroll
-    for (int tt = 0; tt < kTU; ++tt) { sn[tt] = hd[tt] * 0.5; cs[tt] = 1.0 - hd[tt] * 0.25; }
-#else
     if constexpr (MODEL == CCV_MPPI_DIFF_DRIVE && !WIDE) {
         // diff drive: the heading only ever changes by the step's turn w*dt, so its (sin, cos) are ADVANCED by that angle --
         // eight short independent polynomial pairs (no range reduction, no quadrant logic: the host admits this kernel
@@ -593,8 +556,6 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
             }
         }
     }
-#endif
-    CCV_STAMP_AT(ST, 2);
     // ---- 4. cost terms that do not need the window
     if constexpr (COST) {
         if constexpr (!FB) {
@@ -653,7 +614,6 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
         y = y + u[tt][0] * sn[tt] * dt;
     }
     if constexpr (MODE != MODE_COST && !SH::kStage) {
-#if !defined(CCV_ABL_NO_STORE)
         if (A.store_xy) {   // one wave-uniform branch for the 16 stores (padded rows: no `live` predicate, as above)
 #pragma unroll
             for (int tt = 0; tt < kTU; ++tt) {
@@ -661,9 +621,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
                 CCV_STATE_STORE(&A.ys[(size_t)(t0 + tt) * pitch + k], yv[tt]);
             }
         }
-#endif
     }
-    CCV_STAMP_AT(ST, 3);
     S.x = x;
     S.y = y;
     S.yaw = yawv[kTU];
@@ -839,7 +797,6 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
     // ---- exact pruning of the window (pc_prune_window below): the loop runs over the hull [jb, je) of the window points
     // that can be the nearest one for some sample of this wave
     int jb = 0, je = H4;
-#if !defined(CCV_EXP_NO_PRUNE)
     if (A.prune && (prune_on == nullptr || *prune_on)) {
         if (H4 > 64) pc_prune_window<NV, 2>(A, sh, px, py, lane, jb, je);
         else pc_prune_window<NV, 1>(A, sh, px, py, lane, jb, je);
@@ -847,7 +804,6 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
         // and the wave stops testing for the rest of the launch
         if (prune_on && 4 * (je - jb) > 3 * H4) *prune_on = 0;
     }
-#endif
     if constexpr (LEAN) {
         double2 qa[2], qb[2];
         double ca[2], cb[2];
@@ -920,7 +876,7 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
 // Rows are dealt to the two waves; a wave reduces 15 rows at a time through LDS: every lane drops w*u for each row,
 // then lane (r, q) adds 16 of the 64 entries of row r and two shuffles finish the row.  Fixed order => reproducible.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kUpdRB = 15;                  // rows per LDS batch: 15 * 65 doubles fit one wave's half of sh.p
+constexpr int kUpdRB = 15;                  // rows per LDS batch: 15 * 66 doubles fit one wave's half of sh.p
 constexpr int kUpdCH = 4 * kUpdRB;          // rows whose loads are in flight together (120 VGPRs)
 
 // Control rows dealt to the waves of a workgroup in units of BR rows: wave w of NW owns units w, w+NW, ...
@@ -970,8 +926,12 @@ __device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, const SH& s
                                                const int mcount, const double wgt, const int lane, const int kk,
                                                const bool fast_clamp = false) {   // (wave-uniform: see clampd_fast)
     static_assert(RB <= 16 && kUpdCH % RB == 0, "batch size");
-    constexpr int STRIDE = kPcSamples + 1;   // padded row: lanes (r, q) hit different banks
+    // A row is 64 products with one slot of padding after the first 32 (sample k at column k + (k >> 5)) and one at the end:
+    // lane (r, q) then reads its 16 entries of row r from banks that no other lane of its half-wave touches (with 65-double
+    // rows the lanes q and q + 2 of a row met in the same bank: every ds_read_b64 of the sums took two passes)
+    constexpr int STRIDE = kPcSamples + 2;
     const int rr = lane >> 2, q = lane & 3;
+    const int col_w = lane + (lane >> 5), col_r = q * 16 + (q >> 1);
     // one batch: products of rows base .. base+RB-1 (held in v[V0 .. V0+RB-1]) -> LDS -> row sums -> partial
     auto batch = [&](auto V0_, const int base) {
         constexpr int V0 = decltype(V0_)::value;
@@ -995,9 +955,9 @@ __device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, const SH& s
                     static_assert(ROWS::BR % UD == 0 && kUpdCH % UD == 0 && (!LOOP || RB % UD == 0), "row dealing vs control dimension");
                     constexpr int d = (V0 + r) % UD;
                     // (rows past the end: clamped above, never summed)
-                    buf[r * STRIDE + lane] = wgt * pc_control_from_normal_at<MODEL, d, FAST>(A, v[V0 + r], nomv[r]);
+                    buf[r * STRIDE + col_w] = wgt * pc_control_from_normal_at<MODEL, d, FAST>(A, v[V0 + r], nomv[r]);
                 } else {
-                    buf[r * STRIDE + lane] = wgt * v[V0 + r];
+                    buf[r * STRIDE + col_w] = wgt * v[V0 + r];
                 }
             });
         };
@@ -1008,7 +968,7 @@ __device__ __forceinline__ void pc_reduce_rows(const RolloutArgs& A, const SH& s
         double acc = 0.0;
         if (rr < nrows) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc += buf[rr * STRIDE + q * 16 + i];
+            for (int i = 0; i < 16; ++i) acc += buf[rr * STRIDE + col_r + i];
         }
         acc += dpp_move<kDppXor1>(acc);   // the four lanes of a row are one quad
         acc += dpp_move<kDppXor2>(acc);
@@ -1082,20 +1042,10 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
     int prune_on = 1;
     constexpr bool AHEAD = FB && MODE == MODE_FUSED;   // pc_noise_ahead
     __syncthreads();
-#if defined(CCV_STAMP)
-    PcStamps ST;
-    for (int i = 0; i < 8; ++i) ST.acc[i] = 0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ST.last)::"memory");
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
     for (int s = 0; s <= nblocks; ++s) {
-        CCV_STAMP_AT(ST, 7);
         pc_rotate_priority(A, s);
         if (s < nblocks && (s & 1) == wv) {
             // ---------------- produce block s
-#if defined(CCV_EXP_PRIO)
-            __builtin_amdgcn_s_setprio(CCV_EXP_PRIO);
-#endif
             PcState<MODEL> S;
             if (s == 0) {
                 S.x = A.x0[0];
@@ -1128,11 +1078,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
                 }
             }
             bool done = false;
-            if (s * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, s, lane, k, kk, live, kg
-#if defined(CCV_STAMP)
-                                                                              , ST
-#endif
-                                                                              , (AHEAD && s >= 1) ? sh.ahead[wv] : nullptr);
+            if (s * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, s, lane, k, kk, live, kg, (AHEAD && s >= 1) ? sh.ahead[wv] : nullptr);
             if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, s, lane, k, kk, live, kg);
             double(*st)[kPcSamples] = sh.st;
             st[0][lane] = S.x;
@@ -1153,20 +1099,12 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
                 st[10][lane] = S.p_c3;
                 st[11][lane] = S.p_ac;
             }
-            CCV_STAMP_AT(ST, 4);
         }
         if constexpr (COST) {
             if (s >= 1 && ((s - 1) & 1) == wv) {
                 // ---------------- consume block s-1
-#if defined(CCV_EXP_PRIO)
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 const int b = s - 1;
-#if defined(CCV_ABL_NO_DIST)
-                const int nv = 0;
-#else
                 const int nv = min(kTU, nstates - b * kTU);
-#endif
                 if (nv == kTU) pc_consume<kTU, MODEL>(A, sh, cost, b, lane, 0, &prune_on);
                 else if (nv > 0) {
                     switch (nv) {
@@ -1179,7 +1117,6 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
                         default: pc_consume<1, MODEL>(A, sh, cost, b, lane, 0, &prune_on); break;
                     }
                 }
-                CCV_STAMP_AT(ST, 5);
             }
         }
         if constexpr (AHEAD) {
@@ -1188,23 +1125,8 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
                 pc_noise_ahead<MODEL>(A, sh.ahead[wv], s + 1, lane, kg);
         }
         pc_barrier_lds();
-        CCV_STAMP_AT(ST, 6);
     }
     if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
-#if defined(CCV_STAMP)
-    if (A.dbg && lane == 0 && blockIdx.x == 3) {
-        for (int i = 0; i < 8; ++i) A.dbg[wv * 8 + i] = ST.acc[i];
-    }
-    if (A.dbg && lane == 0 && blockIdx.x < 4096) {
-        // per block: [start, loop end wave 0, hw id wave 0, loop end wave 1, hw id wave 1, kernel end wave 0]
-        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
-        unsigned int hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-        unsigned int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
-        if (wv == 0) A.dbg[64 + blockIdx.x * 6 + 0] = rt0;
-        A.dbg[64 + blockIdx.x * 6 + 1 + 2 * wv] = rt1;
-        A.dbg[64 + blockIdx.x * 6 + 2 + 2 * wv] = ((unsigned long long)xcc << 32) | hwid;
-    }
-#endif
     if constexpr (COST) {
         UpdT<MODE> upd[kUpdCH];
         const UpdRows<MODEL> rows{(H - 1) * udim_of(MODEL), wv};
@@ -1221,12 +1143,6 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
         }
         if (A.fuse_update) pc_partial_update<MODEL>(A, sh, upd, rows, mcount, wgt, total, lane, wv, kk, live);
     }
-#if defined(CCV_STAMP)
-    if (A.dbg && lane == 0 && wv == 0 && blockIdx.x < 4096) {
-        __builtin_amdgcn_s_waitcnt(0);
-        A.dbg[64 + blockIdx.x * 6 + 5] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
 }
 
 }  // namespace ccv

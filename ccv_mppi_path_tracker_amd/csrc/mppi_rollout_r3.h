@@ -35,7 +35,6 @@ constexpr int kR3RB = 12;   // rows per LDS transpose batch in the epilogue: 3 w
 template <int MODEL>
 struct R3Shared {
     static constexpr bool kStage = true;
-    static constexpr bool kStageNoise = true;
     static constexpr int kPBuf = 2;
     // (p, ab, c are contiguous and are reused as the epilogue's transpose buffers)
     double p[2][kTU][2][kPcSamples];                       // absolute (x,y) of the 8 states of a block, double buffered
@@ -43,7 +42,6 @@ struct R3Shared {
     double c[kMaxH + 4];
     double cost[kR3Waves][kPcSamples];
     alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u*
-    double us[1][1][kPcSamples];                           // (unused: the building blocks name it)
     float zs[2][kTU * udim_of(MODEL)][kPcSamples];         // normals of a block, double buffered
     // hand-off sequence numbers: [0] blocks the producer has finished writing, [1] / [2] blocks the distance / store wave has
     // taken into registers
@@ -75,7 +73,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     constexpr bool COST = MODE != MODE_ROLLOUT;
     __shared__ R3Shared<MODEL> sh;
-    static_assert(sizeof(sh.p) + sizeof(sh.ab) + sizeof(sh.c) >= kR3Waves * kR3RB * (kPcSamples + 1) * sizeof(double), "epilogue buffers");
+    static_assert(sizeof(sh.p) + sizeof(sh.ab) + sizeof(sh.c) >= kR3Waves * kR3RB * (kPcSamples + 2) * sizeof(double), "epilogue buffers");
     const RolloutArgs A = with_resident_pose(Ak);
     const int H = A.H;
     const int lane = threadIdx.x & 63;
@@ -106,11 +104,6 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
         S.p_v = S.p_rv = S.p_sdir = S.p_c2 = S.p_c3 = S.p_ac = 0.0;
         S.p_cdir = 1.0;
         fast_sincos(A.x0[2], S.sn, S.cs);
-#if defined(CCV_STAMP)
-        PcStamps ST;   // (diagnostic builds: the producer's stamp slots are not read back for this kernel)
-        for (int i = 0; i < 8; ++i) ST.acc[i] = 0;
-        ST.last = 0;
-#endif
         for (int b = 0; b < nblocks; ++b) {
             pc_rotate_priority(A, b);
             if (b >= 2) {   // the buffers of block b last held block b-2: both readers must have taken it
@@ -118,11 +111,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
                 pc_wait_for(seq_store, b - 1);
             }
             bool done = false;
-            if (b * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg
-#if defined(CCV_STAMP)
-                                                                              , ST
-#endif
-            );
+            if (b * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg);
             if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
             pc_publish(seq_ready, b + 1);
         }
@@ -175,7 +164,6 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             pc_publish(seq_store, b + 1);
-#if !defined(CCV_ABL_NO_STORE)
             if constexpr (MODE == MODE_FUSED) {
                 const int nrows = min(kTU, H - 1 - t0) * UD;   // control steps t < H-1
                 static_for<kTU * UD>([&](auto RR) {
@@ -196,7 +184,6 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
                     }
                 }
             }
-#endif
         }
         // the other two waves re-read the control rows in the epilogue: all of this wave's stores are acknowledged before
         // the barrier below
@@ -223,7 +210,7 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
         }
         if (A.fuse_update) {
             // p, ab, c are dead (the loop's last barrier): a private transpose buffer per wave
-            double* buf = &sh.p[0][0][0][0] + wv * (kR3RB * (kPcSamples + 1));
+            double* buf = &sh.p[0][0][0][0] + wv * (kR3RB * (kPcSamples + 2));
             pc_reduce_rows<kR3RB, MODEL>(A, sh, buf, upd, rows, mcount, wgt, lane, kk);
             if (wv == kR3Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
         }

@@ -70,7 +70,6 @@ __device__ __forceinline__ void r4_fetch0(const RolloutArgs& A, T (&v)[kUpdCH], 
 template <int MODEL>
 struct R4Shared {
     static constexpr bool kStage = true;
-    static constexpr bool kStageNoise = true;
     static constexpr int kPBuf = 2;
     // (p, ab, c, zs are contiguous and are reused as the epilogue's transpose buffers)
     double p[2][kTU][2][kPcSamples];                       // absolute (x,y) of the 8 states of a block, double buffered
@@ -79,10 +78,10 @@ struct R4Shared {
     float zs[2][kTU * udim_of(MODEL)][kPcSamples];         // normals of a block, double buffered
     double cost[kR4Waves][kPcSamples];
     alignas(32) double nom[(kMaxH + 8) * udim_of(MODEL)];  // warm start u*
-    double us[1][1][kPcSamples];                           // (unused: the building blocks name it)
     // hand-off sequence numbers: [0] blocks whose normals are in LDS, [1] blocks whose states are in LDS, [2] / [3] blocks the
     // distance / store wave has taken into registers, [4] blocks whose stores to HBM are all acknowledged
     int seq[8];
+    int nan_seen[kR4Waves];   // per wave: a thread of it staged a NaN of the warm start (see clampd_fast)
 };
 
 // The normals of time block b -> LDS (noise wave).  The same grouping of the Philox calls as pc_produce_batched (4 | 3 + 3):
@@ -107,6 +106,85 @@ __device__ __forceinline__ void r4_noise_block(const RolloutArgs& A, SH& sh, con
     }
 }
 
+// One Philox call's four normals of time block b -> LDS (the prologue: block 0's calls are dealt to all four waves, which have
+// nothing else to do until the window and the warm start have arrived).  The same words, the same Box-Muller arithmetic:
+// a normal does not depend on how the calls are grouped.
+template <int MODEL, class SH>
+__device__ __forceinline__ void r4_noise_call(const RolloutArgs& A, SH& sh, const int b, const int call, const int lane, const uint32_t kg) {
+    constexpr int UD = udim_of(MODEL);
+    const Philox4 r = philox4x32_10(kg, (uint32_t)((b * kTU * UD) >> 2) + (uint32_t)call, A.iter_lo, A.iter_hi, A.seed_lo, A.seed_hi);
+    float z[4];
+    box_muller_f32(r.x, r.y, z[0], z[1]);
+    box_muller_f32(r.z, r.w, z[2], z[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sh.zs[b & 1][4 * call + i][lane] = z[i];
+}
+
+// Staging of the window coefficients and the warm start in two halves, so that ALL global loads of the prologue are in flight
+// together (one memory latency instead of two in a row: the kernel arguments were written by the host a moment ago and the
+// warm start by the previous update kernel -- neither is in a cache) and something useful can be done in between.
+template <int MODEL, int NT>
+struct R4Staged {
+    static constexpr int kPerThread = ((kMaxH - 1) * udim_of(MODEL) + 8 + NT - 1) / NT;
+    double wa, wb, wc;
+    double nv[kPerThread];
+    double S;
+};
+template <int MODEL, int NT>
+__device__ __forceinline__ void r4_stage_issue(const RolloutArgs& A, const Window& Wk, const int tid, R4Staged<MODEL, NT>& L) {
+    static_assert(NT >= kMaxH + 4, "one window point per thread");
+    const int H = A.H, R = (H - 1) * udim_of(MODEL);
+    L.wa = L.wb = 0.0;
+    L.wc = INFINITY;
+    if (tid < H) {
+        if (A.frame) {   // (a wave-uniform choice: the resident loop's window, or the copy in the kernel arguments)
+            const Window& W = A.frame->W;
+            L.wa = W.a[tid];
+            L.wb = W.b[tid];
+            L.wc = W.c[tid];
+        } else {
+            L.wa = Wk.a[tid];
+            L.wb = Wk.b[tid];
+            L.wc = Wk.c[tid];
+        }
+    }
+    const double* src = A.pending_vec ? A.pending_vec + 1 : A.nominal;
+    L.S = A.pending_vec ? A.pending_vec[0] : 1.0;
+#pragma unroll
+    for (int i = 0; i < R4Staged<MODEL, NT>::kPerThread; ++i) {
+        const int j = tid + i * NT;
+        L.nv[i] = j < R ? src[j] : 0.0;
+    }
+}
+// ... and the LDS half (what stage_window + pc_stage_nominal write, the same values); returns whether a value this thread
+// staged is NaN (clampd_fast)
+template <int MODEL, int NT, class SH>
+__device__ __forceinline__ bool r4_stage_commit(const RolloutArgs& A, SH& sh, const int tid, const R4Staged<MODEL, NT>& L) {
+    const int H = A.H, H4 = (H + 3) & ~3, R = (H - 1) * udim_of(MODEL);
+    if (tid < H4) {
+        sh.ab[tid] = make_double2(L.wa, L.wb);
+        sh.c[tid] = L.wc;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < R4Staged<MODEL, NT>::kPerThread; ++i) {
+        const int j = tid + i * NT;
+        if (j < R + 8) {
+            // K sharded over devices: the all-reduced [sum w, sum w*u] has not been divided yet -- pc_stage_nominal's division,
+            // bit for bit
+            const double v = (A.pending_vec && j < R) ? L.nv[i] / L.S : L.nv[i];
+            sh.nom[j] = v;
+            bad |= v != v;
+            if (blockIdx.x == 0 && j < R) {
+                if (A.pending_vec) A.nominal_w[j] = v;
+                A.nominal_used[j] = v;   // (the normals are stored, not the controls: kept with them)
+            }
+        }
+    }
+    if (A.pending_vec && blockIdx.x == 0 && tid == 0) A.stats_w[0] = L.S;
+    return bad;
+}
+
 // The per-lane sample indices, made afresh where a role (or the epilogue) needs them: five values that are live from the
 // first instruction to the last would otherwise be spilled at 128 registers (the asm statement keeps the compiler from
 // merging the copies back into one).
@@ -126,31 +204,6 @@ __device__ __forceinline__ R4Lane r4_lane(const RolloutArgs& A) {
     return L;
 }
 
-// Diagnostic builds (-DCCV_STAMP, tools/stamps_r4.py): six 100 MHz timestamps per workgroup -- [0] kernel entry, [1] the
-// dynamics wave has published block 0, [2] its loop is through, [3] the distance wave's loop is through, [4] wave 0 is past
-// the barrier, [5] wave 0 is through the epilogue.
-#if defined(CCV_STAMP)
-#define R4_STAMP(slot)                                                                                                \
-    do {                                                                                                              \
-        if (A.dbg && blockIdx.x < 4096) A.dbg[64 + blockIdx.x * 6 + (slot)] = __builtin_amdgcn_s_memrealtime();       \
-    } while (0)
-#else
-#define R4_STAMP(slot) do {} while (0)
-#endif
-// -DCCV_STAMP=2: the six slots cover the start of the kernel instead -- [0] entry, [1] first barrier passed, [2] staging
-// barrier passed, [3] block 0's normals published, [4] the dynamics wave has them, [5] it has published block 0.
-#if defined(CCV_STAMP) && CCV_STAMP + 0 == 4   // (the epilogue: [0] wave 0 past the barrier, [1] / [3] wave 0 / 2 has its weight,
-                                               //  [2] / [4] / [5] wave 0 / 2 / 3 done; STAMP_SET=epi)
-#define R4_STAMP_LOOP(slot) do {} while (0)
-#define R4_STAMP_FILL(slot) do {} while (0)
-#elif defined(CCV_STAMP) && CCV_STAMP + 0 == 2
-#define R4_STAMP_LOOP(slot) do {} while (0)
-#define R4_STAMP_FILL(slot) R4_STAMP(slot)
-#else
-#define R4_STAMP_LOOP(slot) R4_STAMP(slot)
-#define R4_STAMP_FILL(slot) do {} while (0)
-#endif
-
 // WIDE (diff drive, fused iteration): full-range sin / cos of every heading, for |w|max dt > pi/4 (pc_produce_batched)
 template <int MODEL, int MODE, bool WIDE = false>
 __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutArgs Ak, const Window Wk) {
@@ -160,44 +213,73 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     static_assert(!FB, "diff drive and steering only");
     static_assert(!WIDE || (MODEL == CCV_MPPI_DIFF_DRIVE && MODE == MODE_FUSED), "the wide-turn form exists for the fused diff-drive iteration");
     __shared__ R4Shared<MODEL> sh;
-    static_assert(offsetof(R4Shared<MODEL>, zs) + sizeof(sh.zs) >= kR4Waves * kR4RB * (kPcSamples + 1) * sizeof(double), "epilogue buffers");
+    static_assert(offsetof(R4Shared<MODEL>, zs) + sizeof(sh.zs) >= kR4Waves * kR4RB * (kPcSamples + 2) * sizeof(double), "epilogue buffers");
+    touch_rollout_args();
     const RolloutArgs A = with_resident_pose(Ak);
+    // The prologue runs in all sixteen waves of a CU at once and SIMD arbitration is oldest first: the workgroup dispatched last
+    // to a CU was through it 1.5 us after the first (stamps: staging barrier passed at 1.4 / 1.7 / 2.0 / 3.0 us by dispatch
+    // rank) and carried that lag to the end of the kernel, which ends with the slowest.  Until the loops' rotation takes over,
+    // the younger workgroup has the higher priority.
+    if (A.prio_rotate) pc_set_priority((int)blockIdx.x / A.cu_count);
     const int H = A.H;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#if !(defined(CCV_STAMP) && CCV_STAMP + 0 == 4)
-    if (wv == 0) R4_STAMP(0);   // (both stamp sets)
-#endif
+    if (wv == 0) CCV_DIAG_STAMP(A, 0);
     const int nblocks = (H + kTU - 1) / kTU;
     const int nstates = H;   // states that reach the path cost (dd:199)
     // blocks whose 8 steps all carry controls: their normals come from the noise wave (the last, partial block is the
     // dynamics wave's own: pc_produce)
     const int nfull = MODE == MODE_FUSED ? (H - 1) / kTU : 0;
     int* const seq_noise = &sh.seq[0];
-    if (threadIdx.x < 8) sh.seq[threadIdx.x] = 0;
-    __syncthreads();   // (the sequence numbers are zero before anything is published or seq[5], the "NaN in u*" flag, raised)
-    if (wv == 1) R4_STAMP_FILL(1);
+    // ---------------- prologue: ONE barrier.  Every thread issues its loads of the window and the warm start, the four waves
+    // make the normals of time block 0 meanwhile -- its Philox calls dealt round (a lone wave needs as long for four
+    // interleaved calls as the memory latency lasts; four waves are through theirs well inside it) -- and the dynamics wave
+    // its own set-up; then the staged values go to LDS.  The barrier publishes all of it, block 0's normals included.
+    // (sequence numbers: zero, but "normals of block 0 are in LDS"; seq[5..7] are not used any more)
+    if (threadIdx.x < 8) sh.seq[threadIdx.x] = (threadIdx.x == 0 && nfull > 0) ? 1 : 0;
+    PcState<MODEL> S;          // (the dynamics wave's rollout state)
+    bool bad_nominal = false;
     if constexpr (MODE == MODE_FUSED) {
-        // the window and the warm start are staged by three waves; the noise wave needs neither and makes the normals of block
-        // 0 meanwhile -- the dynamics wave waits for both anyway, now for the longer of the two instead of their sum
-        if (wv == 0) {
-            if (nfull > 0) {
-                const R4Lane L = r4_lane(A);
-                r4_noise_block<MODEL>(A, sh, 0, L.lane, L.kg);
-                pc_publish(seq_noise, 1);
-                R4_STAMP_FILL(3);
-            }
-        } else {
-            const int tid = (int)threadIdx.x - 64;
-            stage_window(A, Wk, sh, (kR4Waves - 1) * 64, tid);
-            if (pc_stage_nominal<MODEL>(A, sh, (kR4Waves - 1) * 64, tid)) sh.seq[5] = 1;
+        R4Staged<MODEL, kR4Waves * 64> staged;
+        r4_stage_issue<MODEL>(A, Wk, (int)threadIdx.x, staged);
+        if (nfull > 0) {
+            constexpr int NCALL = kTU * UD / 4;
+            const R4Lane L = r4_lane(A);
+            for (int c = wv; c < NCALL; c += kR4Waves) r4_noise_call<MODEL>(A, sh, 0, c, L.lane, L.kg);
         }
+        if (wv == 0) CCV_DIAG_STAMP(A, 3);
+        if (wv == 1) {
+            S.x = A.x0[0];
+            S.y = A.x0[1];
+            S.yaw = A.x0[2];
+            S.roll = A.x0[3];
+            S.pitch = A.x0[4];
+            S.p_v = S.p_rv = S.p_sdir = S.p_c2 = S.p_c3 = S.p_ac = 0.0;
+            S.p_cdir = 1.0;
+            fast_sincos(A.x0[2], S.sn, S.cs);
+            CCV_DIAG_STAMP(A, 1);
+        }
+        bad_nominal = r4_stage_commit<MODEL>(A, sh, (int)threadIdx.x, staged);
+        // a NaN in the warm start: every wave says what its threads saw, every wave reads all four words after the barrier
+        const bool wave_bad = __builtin_amdgcn_ballot_w64(bad_nominal) != 0ull;
+        if (r4_lane(A).lane == 0) sh.nan_seen[wv] = wave_bad ? 1 : 0;
     } else {
         if constexpr (COST) stage_window(A, Wk, sh, kR4Waves * 64);
+        if (wv == 1) {
+            S.x = A.x0[0];
+            S.y = A.x0[1];
+            S.yaw = A.x0[2];
+            S.roll = A.x0[3];
+            S.pitch = A.x0[4];
+            S.p_v = S.p_rv = S.p_sdir = S.p_c2 = S.p_c3 = S.p_ac = 0.0;
+            S.p_cdir = 1.0;
+            fast_sincos(A.x0[2], S.sn, S.cs);
+        }
     }
     __syncthreads();
-    if (wv == 1) R4_STAMP_FILL(2);
+    if (wv == 1) CCV_DIAG_STAMP(A, 2);
     // two-instruction clamps (clampd_fast): the host has checked sigma and the bounds, the staging found no NaN in u*
-    const bool fast_clamp = MODE == MODE_FUSED && A.fast_clamp && __builtin_amdgcn_readfirstlane(sh.seq[5]) == 0;
+    const bool fast_clamp = MODE == MODE_FUSED && A.fast_clamp &&
+                            __builtin_amdgcn_readfirstlane(sh.nan_seen[0] | sh.nan_seen[1] | sh.nan_seen[2] | sh.nan_seen[3]) == 0;
     int* const seq_ready = &sh.seq[1];
     int* const seq_dist = &sh.seq[2];
     int* const seq_store = &sh.seq[3];
@@ -222,7 +304,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
             const int lane = L.lane;
             const uint32_t kg = L.kg;
             for (int b = 1; b < nfull; ++b) {   // (block 0: above, beside the staging)
-                pc_rotate_priority(A, b);
+                r4_rotate_priority(A, b, 0);
                 if (b >= 2) {   // zs[b & 1] last held block b-2: the dynamics wave is through it, the store wave has loaded it
                     pc_wait_for(seq_ready, b - 1);
                     pc_wait_for(seq_store, b - 1);
@@ -230,6 +312,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                 r4_noise_block<MODEL>(A, sh, b, lane, kg);
                 pc_publish(seq_noise, b + 1);
             }
+            CCV_DIAG_STAMP(A, 15);
         }
         if constexpr (COST) sh.cost[0][r4_lane(A).lane] = 0.0;
         if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
@@ -241,72 +324,44 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         const bool live = L.live;
         const uint32_t kg = L.kg;
         double cost = 0.0;
-        PcState<MODEL> S;
-        S.x = A.x0[0];
-        S.y = A.x0[1];
-        S.yaw = A.x0[2];
-        S.roll = A.x0[3];
-        S.pitch = A.x0[4];
-        S.p_v = S.p_rv = S.p_sdir = S.p_c2 = S.p_c3 = S.p_ac = 0.0;
-        S.p_cdir = 1.0;
-        fast_sincos(A.x0[2], S.sn, S.cs);
-#if defined(CCV_STAMP)
-        PcStamps ST;
-        for (int i = 0; i < 8; ++i) ST.acc[i] = 0;
-        ST.last = 0;
-#endif
         for (int b = 0; b < nblocks; ++b) {
-            pc_rotate_priority(A, b + 1);
+            r4_rotate_priority(A, b, 1);
             if (b >= 2) {   // the buffers of block b last held block b-2: both readers must have taken it
                 pc_wait_for(seq_dist, b - 1);
                 pc_wait_for(seq_store, b - 1);
             }
             if (b < nfull) {
                 pc_wait_for(seq_noise, b + 1);
-                if (b == 0) R4_STAMP_FILL(4);
+                if (b == 0) CCV_DIAG_STAMP(A, 4);
                 // (two instantiations: a NaN in the warm start is rare, but its results are to be the other kernels' bits too)
                 if (fast_clamp)
-                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg
-#if defined(CCV_STAMP)
-                                                                         , ST
-#endif
-                    );
+                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg);
                 else
-                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, false, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg
-#if defined(CCV_STAMP)
-                                                                          , ST
-#endif
-                    );
+                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, false, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg);
             } else {
                 bool done = false;
                 if (MODE != MODE_FUSED && b * kTU + kTU <= H - 1)
-                    done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg
-#if defined(CCV_STAMP)
-                                                           , ST
-#endif
-                    );
+                    done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg);
                 if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
             }
             pc_publish(seq_ready, b + 1);
-            if (b == 0) {
-                R4_STAMP_LOOP(1);
-                R4_STAMP_FILL(5);
-            }
+            if (b == 0) CCV_DIAG_STAMP(A, 5);
         }
-        R4_STAMP_LOOP(2);
+        CCV_DIAG_STAMP(A, 6);
         if constexpr (COST) sh.cost[1][lane] = cost;
         if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
         early_fetch();
     } else if (wv == 2) {
         // ---------------- distance wave: the states of block b as soon as the dynamics wave has published it
+        // (round 3 tried handing every second one of the last blocks to the noise wave, which is idle from two thirds of the
+        //  kernel on: +1.5 us -- the loop is paced by the stores, 83 MB at the 5.1 TB/s this chip writes, not by this wave)
         int prune_on = 1;
         const int lane = r4_lane(A).lane;
         double cost = 0.0;
         for (int b = 0; b < nblocks; ++b) {
-            pc_rotate_priority(A, b + 2);
+            r4_rotate_priority(A, b, 2);
             pc_wait_for(seq_ready, b + 1);
             bool taken = false;
-#if !defined(CCV_ABL_NO_DIST)
             if constexpr (COST) {
                 const int nv = min(kR3CStates, nstates - b * kTU);
                 taken = nv > 0;
@@ -322,10 +377,10 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                     default: break;
                 }
             }
-#endif
             if (!taken) pc_publish(seq_dist, b + 1);   // (nothing of this block reaches the path cost)
+            if (b == 0) CCV_DIAG_STAMP(A, 14);
         }
-        R4_STAMP_LOOP(3);
+        CCV_DIAG_STAMP(A, 7);
         if constexpr (COST) sh.cost[2][lane] = cost;
     } else {
         // ---------------- store wave: normals (MODE_FUSED) and states (not in MODE_COST) of block b, LDS -> registers ->
@@ -335,7 +390,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         const int lane = L.lane;
         const uint32_t koff4 = (uint32_t)L.k * 4u, koff8 = (uint32_t)L.k * 8u;
         for (int b = 0; b < nblocks; ++b) {
-            pc_rotate_priority(A, b + 3);
+            r4_rotate_priority(A, b, 3);
             pc_wait_for(seq_ready, b + 1);
             const int t0 = b * kTU;
             float zv[kTU * UD];
@@ -353,7 +408,6 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             pc_publish(seq_store, b + 1);
-#if !defined(CCV_ABL_NO_STORE)
             // (the row pitch in bytes stays below 4 GB by construction: 32-bit lane offsets)
             if constexpr (MODE == MODE_FUSED) {
                 const int nrows = min(kTU, H - 1 - t0) * UD;   // control steps t < H-1
@@ -378,7 +432,6 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                     }
                 }
             }
-#endif
             if constexpr (MODE == MODE_FUSED) {
                 // all stores of the blocks before this one are acknowledged once no more than this block's own are
                 // outstanding (vector-memory operations complete in order); a partial block waits for everything
@@ -395,6 +448,8 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (COST) sh.cost[3][lane] = 0.0;
     }
+    // (the epilogue at equal priorities: youngest-first there, as in the prologue, was measured 1.4 us SLOWER -- the epilogue is
+    //  bound by LDS bandwidth, and strict priorities only serialise it)
     if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
     if constexpr (COST) {
         const int R = (H - 1) * UD;
@@ -405,10 +460,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         // the one barrier of the kernel: every wave is through its loop (the store wave with all its stores acknowledged),
         // the cost parts are in LDS, and p / ab / c / zs are dead
         pc_barrier_lds();
-        if (wv == 0) R4_STAMP_LOOP(4);
-#if defined(CCV_STAMP) && CCV_STAMP + 0 == 4
-        if (wv == 0 && A.dbg && blockIdx.x < 4096) A.dbg[64 + blockIdx.x * 6 + 0] = __builtin_amdgcn_s_memrealtime();
-#endif
+        if (wv == 0) CCV_DIAG_STAMP(A, 8);
         if ((MODE != MODE_FUSED || wv >= 2) && mcount > 0) r4_fetch0(A, upd, rows, kk);
         const double total = ((sh.cost[0][lane] + sh.cost[1][lane]) + sh.cost[2][lane]) + sh.cost[3][lane];
         const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
@@ -416,22 +468,16 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
             A.cost[k] = total;
             A.w[k] = wgt;
         }
-#if defined(CCV_STAMP) && CCV_STAMP + 0 == 4
-        {
-            double keep = wgt;
-            asm volatile("" : "+v"(keep));
-            if (A.dbg && blockIdx.x < 4096 && (wv == 0 || wv == 2)) A.dbg[64 + blockIdx.x * 6 + (wv == 0 ? 1 : 3)] = __builtin_amdgcn_s_memrealtime();
-        }
-#endif
+        if (wv == 0) CCV_DIAG_STAMP_VALUE(A, 9, wgt);
+        if (wv == 2) CCV_DIAG_STAMP_VALUE(A, 11, wgt);
         if (A.fuse_update) {
-            double* buf = &sh.p[0][0][0][0] + wv * (kR4RB * (kPcSamples + 1));
+            double* buf = &sh.p[0][0][0][0] + wv * (kR4RB * (kPcSamples + 2));
             pc_reduce_rows<kR4RB, MODEL, true>(A, sh, buf, upd, rows, mcount, wgt, lane, kk, fast_clamp);
             if (wv == kR4Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
         }
-        if (wv == 0) R4_STAMP_LOOP(5);
-#if defined(CCV_STAMP) && CCV_STAMP + 0 == 4
-        if (A.dbg && blockIdx.x < 4096 && wv != 1) A.dbg[64 + blockIdx.x * 6 + (wv == 0 ? 2 : wv == 2 ? 4 : 5)] = __builtin_amdgcn_s_memrealtime();
-#endif
+        if (wv == 0) CCV_DIAG_STAMP(A, 10);
+        if (wv == 2) CCV_DIAG_STAMP(A, 12);
+        if (wv == 3) CCV_DIAG_STAMP(A, 13);
     }
 }
 

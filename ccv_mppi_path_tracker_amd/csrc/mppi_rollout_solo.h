@@ -17,7 +17,6 @@ namespace ccv {
 template <int MODEL>
 struct SoloShared {
     static constexpr bool kStage = false;
-    static constexpr bool kStageNoise = false;
     static constexpr int kPBuf = 1;                        // produced and consumed by the same wave, one after the other
     double2 ab[kMaxH + 4];                                 // window coefficients, padded to a multiple of 4 points
     double c[kMaxH + 4];
@@ -30,7 +29,7 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
     static_assert(MODE == MODE_FUSED, "the stage-wise modes use k_rollout_pc");
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     __shared__ SoloShared<MODEL> sh;
-    static_assert(sizeof(sh.p) >= kUpdRB * (kPcSamples + 1) * sizeof(double), "epilogue buffer");
+    static_assert(sizeof(sh.p) >= kUpdRB * (kPcSamples + 2) * sizeof(double), "epilogue buffer");
     const RolloutArgs A = with_resident_pose(Ak);
     const int H = A.H;
     const int lane = threadIdx.x;
@@ -57,29 +56,16 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
     S.p_cdir = 1.0;
     fast_sincos(A.x0[2], S.sn, S.cs);
     __syncthreads();   // (one wave: the staged window and warm start are visible to all its lanes)
-#if defined(CCV_STAMP)
-    PcStamps ST;
-    for (int i = 0; i < 8; ++i) ST.acc[i] = 0;
-    ST.last = 0;
-#endif
     for (int b = 0; b < nblocks; ++b) {
         // ---------------- states and controls of steps 8b .. 8b+7
         bool done = false;
         if (b * kTU + kTU <= H - 1) {
             if (fast_clamp)
-                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, true, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg
-#if defined(CCV_STAMP)
-                                                                                      , ST
-#endif
-                );
+                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, true, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg);
             else if constexpr (!FB)   // (a second instantiation, so that a NaN in the warm start gives the multi-wave kernels'
                                       //  bits; full body has no registers for it -- its NaN case takes pc_produce below, whose
                                       //  sin / cos differ from the block path's in the last place)
-                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, false, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg
-#if defined(CCV_STAMP)
-                                                                                       , ST
-#endif
-                );
+                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, false, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg);
         }
         if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
         // ---------------- their distance to the window
