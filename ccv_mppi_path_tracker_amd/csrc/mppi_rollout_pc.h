@@ -72,7 +72,7 @@ __device__ __forceinline__ bool pc_stage_nominal(const RolloutArgs& A, SH& sh, c
         // K sharded over devices: the all-reduced [sum w, sum w*u] has not been divided yet -- do it here (the division
         // k_apply_partials would do, bit for bit) instead of spending a kernel launch on 100 quotients
         const double S = A.pending_vec[0];
-        for (int j = tid; j < R + 8; j += nthreads) {
+        for (int j = tid; j < R + kTU * udim_of(MODEL); j += nthreads) {
             const double v = j < R ? A.pending_vec[1 + j] / S : 0.0;
             sh.nom[j] = v;
             bad |= v != v;
@@ -84,7 +84,7 @@ __device__ __forceinline__ bool pc_stage_nominal(const RolloutArgs& A, SH& sh, c
         if (blockIdx.x == 0 && tid == 0) A.stats_w[0] = S;
         return bad;
     }
-    for (int j = tid; j < R + 8; j += nthreads) {
+    for (int j = tid; j < R + kTU * udim_of(MODEL); j += nthreads) {
         const double v = j < R ? A.nominal[j] : 0.0;
         sh.nom[j] = v;
         bad |= v != v;
@@ -367,11 +367,22 @@ __device__ __forceinline__ void pc_noise_ahead(const RolloutArgs& A, float (*slo
 // WIDE (diff drive): sin / cos of every heading evaluated in full (fast_sincos_n, as steering does) instead of advanced by
 // the step's turn -- for loop periods beyond |w|max dt = pi/4, where the short polynomials of the rotation form are not
 // valid (the node measures dt, dd:346-348: one slow tick must not cost a different, twice as slow kernel).
-template <int MODEL, int MODE, class SH, bool ZLDS = false, bool FASTCLAMP = false, bool WIDE = false>
+// PARTIAL: the horizon's last block when fewer than 8 of its steps carry controls (nctl = H - 1 - 8 b of them, 1 .. 7; the
+// block's states are t0 .. t0 + nctl, the last one t = H - 1).  The whole batch is computed as for a full block -- the normals
+// past row (H-1) u_dim are drawn and dropped, the warm start reads as 0 there -- and only what leaves the block is masked:
+// stores, cost terms (dd / sd: the Q1 phantom term at t = H - 1), the step-range conditions of the full-body terms.  The
+// reference defaults run H = 15: six of fourteen control steps used to go through the step-by-step path (pc_produce), whose
+// chains (Philox -> Box-Muller -> sin/cos -> position, one step after the other) a lone wave waits out one by one.
+// (worth it from kPartialMin steps on: a block of one or two steps is quicker step by step than as a batch of eight -- C2's
+//  H - 1 = 49 leaves one step, and batching it cost the four-wave kernel 1.6 us)
+constexpr int kPartialMin = 4;
+template <int MODEL, int MODE, class SH, bool ZLDS = false, bool FASTCLAMP = false, bool WIDE = false, bool PARTIAL = false>
 __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh, PcState<MODEL>& S, double& cost,
                                                    const int b, const int lane, const int k, const int kk, const bool live,
                                                    const uint32_t kg,
-                                                   const float (*ahead)[kPcSamples] = nullptr) {   // pc_noise_ahead's slot
+                                                   const float (*ahead)[kPcSamples] = nullptr,   // pc_noise_ahead's slot
+                                                   const int nctl_in = kTU) {
+    const int nctl = PARTIAL ? nctl_in : kTU;   // steps of this block that carry controls (wave-uniform)
     constexpr int UD = udim_of(MODEL);
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     constexpr bool COST = MODE != MODE_ROLLOUT;
@@ -417,7 +428,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
                 } else {
                     // no `live` predicate: rows are padded to a multiple of 64 samples (pitch), lanes past K write their
                     // padding slot -- a branch per store would cut this block into pieces the scheduler cannot interleave
-                    A.z[(size_t)(t0 * UD + nloc) * pitch + k] = z[i];
+                    if (!PARTIAL || tt < nctl) A.z[(size_t)(t0 * UD + nloc) * pitch + k] = z[i];
                 }
             });
         };
@@ -437,7 +448,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
 #pragma unroll
         for (int tt = 0; tt < kTU; ++tt)
 #pragma unroll
-            for (int d = 0; d < UD; ++d) u[tt][d] = A.u[(size_t)((t0 + tt) * UD + d) * pitch + kk];
+            for (int d = 0; d < UD; ++d) u[tt][d] = (!PARTIAL || tt < nctl) ? A.u[(size_t)((t0 + tt) * UD + d) * pitch + kk] : 0.0;
     }
     // ---- 2. heading (roll, pitch) recurrences: yaw[t+1] = yaw[t] + w[t]*dt (dd:108, fb:449-451)
     double yawv[kTU + 1], rollv[FB ? kTU + 1 : 1], pitchv[FB ? kTU + 1 : 1];
@@ -560,7 +571,16 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
     if constexpr (COST) {
         if constexpr (!FB) {
 #pragma unroll
-            for (int tt = 0; tt < kTU; ++tt) cost += A.w_v * ((u[tt][0] - A.v_ref) * (u[tt][0] - A.v_ref));   // dd:204-206
+            for (int tt = 0; tt < kTU; ++tt) {
+                const double cv = A.w_v * ((u[tt][0] - A.v_ref) * (u[tt][0] - A.v_ref));   // dd:204-206
+                if constexpr (PARTIAL) {
+                    // t == H-1: the reference reads control index H-1, one past the end (dd:199,204): defined as 0.0 (Q1)
+                    const double phantom = A.w_v * ((0.0 - A.v_ref) * (0.0 - A.v_ref));
+                    cost += tt < nctl ? cv : (tt == nctl ? phantom : 0.0);
+                } else {
+                    cost += cv;
+                }
+            }
         } else {
             const double mgz = A.fb_mass * A.fb_gz;   // (mass*gravity_).z
 #pragma unroll
@@ -582,7 +602,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
                     const double zmp_y = mo_x / mgz;                                             // fb:601
                     const double cz = A.w_zmp * zmp_y * zmp_y;                                   // fb:416
                     const double cr = A.w_rollv * (u[tt][3] - S.p_rv) * (u[tt][3] - S.p_rv);     // fb:418
-                    const bool in = t >= 1;
+                    const bool in = t >= 1 && (!PARTIAL || tt < nctl);   // (index t-1 <= H-3)
                     cost += in ? cz : 0.0;
                     cost += in ? cr : 0.0;
                 }
@@ -617,8 +637,10 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
         if (A.store_xy) {   // one wave-uniform branch for the 16 stores (padded rows: no `live` predicate, as above)
 #pragma unroll
             for (int tt = 0; tt < kTU; ++tt) {
-                CCV_STATE_STORE(&A.xs[(size_t)(t0 + tt) * pitch + k], xv[tt]);
-                CCV_STATE_STORE(&A.ys[(size_t)(t0 + tt) * pitch + k], yv[tt]);
+                if (!PARTIAL || tt <= nctl) {   // states t <= H-1
+                    CCV_STATE_STORE(&A.xs[(size_t)(t0 + tt) * pitch + k], xv[tt]);
+                    CCV_STATE_STORE(&A.ys[(size_t)(t0 + tt) * pitch + k], yv[tt]);
+                }
             }
         }
     }
@@ -1077,9 +1099,11 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
                     S.p_ac = st[11][lane];
                 }
             }
-            bool done = false;
-            if (s * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, s, lane, k, kk, live, kg, (AHEAD && s >= 1) ? sh.ahead[wv] : nullptr);
-            if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, s, lane, k, kk, live, kg);
+            const int nctl = min(kTU, H - 1 - s * kTU);   // steps of this block that carry controls
+            const float(*ahead)[kPcSamples] = (AHEAD && s >= 1) ? sh.ahead[wv] : nullptr;
+            if (nctl == kTU) pc_produce_batched<MODEL, MODE>(A, sh, S, cost, s, lane, k, kk, live, kg, ahead);
+            else if (nctl >= kPartialMin) pc_produce_batched<MODEL, MODE, PcShared<MODEL>, false, false, false, true>(A, sh, S, cost, s, lane, k, kk, live, kg, ahead, nctl);
+            else pc_produce<MODEL, MODE, false>(A, sh, S, cost, s, lane, k, kk, live, kg);   // (a short tail, or the final state only)
             double(*st)[kPcSamples] = sh.st;
             st[0][lane] = S.x;
             st[1][lane] = S.y;
@@ -1121,7 +1145,7 @@ __global__ __launch_bounds__(kPcWaves * 64, 2) void k_rollout_pc(const RolloutAr
         }
         if constexpr (AHEAD) {
             // the wave that is not producing now produces block s+1 next: part of that block's normals, made in its idle time
-            if (((s + 1) & 1) == wv && s + 1 < nblocks && (s + 1) * kTU + kTU <= H - 1)
+            if (((s + 1) & 1) == wv && s + 1 < nblocks && H - 1 - (s + 1) * kTU >= kPartialMin)   // (a block made as a batch, full or partial)
                 pc_noise_ahead<MODEL>(A, sh.ahead[wv], s + 1, lane, kg);
         }
         pc_barrier_lds();

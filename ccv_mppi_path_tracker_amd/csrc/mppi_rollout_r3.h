@@ -110,9 +110,10 @@ __global__ __launch_bounds__(kR3Waves * 64, 3) void k_rollout_r3(const RolloutAr
                 pc_wait_for(seq_dist, b - 1);
                 pc_wait_for(seq_store, b - 1);
             }
-            bool done = false;
-            if (b * kTU + kTU <= H - 1) done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg);
-            if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
+            const int nctl = min(kTU, H - 1 - b * kTU);   // steps of this block that carry controls
+            if (nctl == kTU) pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg);
+            else if (nctl >= kPartialMin) pc_produce_batched<MODEL, MODE, R3Shared<MODEL>, false, false, false, true>(A, sh, S, cost, b, lane, k, kk, live, kg, nullptr, nctl);
+            else pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);   // (a short tail, or the final state only)
             pc_publish(seq_ready, b + 1);
         }
     } else if (wv == 1) {

@@ -125,7 +125,7 @@ __device__ __forceinline__ void r4_noise_call(const RolloutArgs& A, SH& sh, cons
 // warm start by the previous update kernel -- neither is in a cache) and something useful can be done in between.
 template <int MODEL, int NT>
 struct R4Staged {
-    static constexpr int kPerThread = ((kMaxH - 1) * udim_of(MODEL) + 8 + NT - 1) / NT;
+    static constexpr int kPerThread = ((kMaxH - 1 + kTU) * udim_of(MODEL) + NT - 1) / NT;
     double wa, wb, wc;
     double nv[kPerThread];
     double S;
@@ -169,7 +169,7 @@ __device__ __forceinline__ bool r4_stage_commit(const RolloutArgs& A, SH& sh, co
 #pragma unroll
     for (int i = 0; i < R4Staged<MODEL, NT>::kPerThread; ++i) {
         const int j = tid + i * NT;
-        if (j < R + 8) {
+        if (j < R + kTU * udim_of(MODEL)) {   // (zeros past the last row: a partial last block reads them, pc_produce_batched)
             // K sharded over devices: the all-reduced [sum w, sum w*u] has not been divided yet -- pc_stage_nominal's division,
             // bit for bit
             const double v = (A.pending_vec && j < R) ? L.nv[i] / L.S : L.nv[i];
@@ -205,13 +205,17 @@ __device__ __forceinline__ R4Lane r4_lane(const RolloutArgs& A) {
 }
 
 // WIDE (diff drive, fused iteration): full-range sin / cos of every heading, for |w|max dt > pi/4 (pc_produce_batched)
-template <int MODEL, int MODE, bool WIDE = false>
+// TAIL (fused iteration): the horizon's last block carries kPartialMin .. 7 control steps and is made as a masked batch
+// (pc_produce_batched, PARTIAL) -- an instantiation of its own, chosen by the launcher from H: with the masked producer merely
+// present in the dynamics wave's loop, the kernel that never runs it (C2: H - 1 = 6 * 8 + 1) was 1.3 us slower.
+template <int MODEL, int MODE, bool WIDE = false, bool TAIL = false>
 __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutArgs Ak, const Window Wk) {
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     constexpr bool COST = MODE != MODE_ROLLOUT;
     constexpr int UD = udim_of(MODEL);
     static_assert(!FB, "diff drive and steering only");
     static_assert(!WIDE || (MODEL == CCV_MPPI_DIFF_DRIVE && MODE == MODE_FUSED), "the wide-turn form exists for the fused diff-drive iteration");
+    static_assert(!TAIL || MODE == MODE_FUSED, "the stage-wise modes carry the masked producer anyway");
     __shared__ R4Shared<MODEL> sh;
     static_assert(offsetof(R4Shared<MODEL>, zs) + sizeof(sh.zs) >= kR4Waves * kR4RB * (kPcSamples + 2) * sizeof(double), "epilogue buffers");
     touch_rollout_args();
@@ -226,9 +230,10 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     if (wv == 0) CCV_DIAG_STAMP(A, 0);
     const int nblocks = (H + kTU - 1) / kTU;
     const int nstates = H;   // states that reach the path cost (dd:199)
-    // blocks whose 8 steps all carry controls: their normals come from the noise wave (the last, partial block is the
-    // dynamics wave's own: pc_produce)
-    const int nfull = MODE == MODE_FUSED ? (H - 1) / kTU : 0;
+    // blocks whose controls are made as a batch: their normals come from the noise wave -- all eight steps' worth, also for a
+    // last block that uses fewer but at least kPartialMin (pc_produce_batched, PARTIAL); a shorter tail is the dynamics wave's
+    // own, step by step (pc_produce)
+    const int nfull = MODE == MODE_FUSED ? (TAIL ? (H - 1 + kTU - kPartialMin) / kTU : (H - 1) / kTU) : 0;
     int* const seq_noise = &sh.seq[0];
     // ---------------- prologue: ONE barrier.  Every thread issues its loads of the window and the warm start, the four waves
     // make the normals of time block 0 meanwhile -- its Philox calls dealt round (a lone wave needs as long for four
@@ -330,19 +335,28 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
                 pc_wait_for(seq_dist, b - 1);
                 pc_wait_for(seq_store, b - 1);
             }
+            const int nctl = min(kTU, H - 1 - b * kTU);   // steps of this block that carry controls
             if (b < nfull) {
                 pc_wait_for(seq_noise, b + 1);
                 if (b == 0) CCV_DIAG_STAMP(A, 4);
-                // (two instantiations: a NaN in the warm start is rare, but its results are to be the other kernels' bits too)
-                if (fast_clamp)
-                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg);
-                else
-                    pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, false, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg);
+                // (two instantiations each: a NaN in the warm start is rare, but its results are to be the other kernels' bits too)
+                if (!TAIL || nctl == kTU) {
+                    if (fast_clamp)
+                        pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg);
+                    else
+                        pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, false, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg);
+                } else if constexpr (TAIL) {
+                    if (fast_clamp)
+                        pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, true, WIDE, true>(A, sh, S, cost, b, lane, k, kk, live, kg, nullptr, nctl);
+                    else
+                        pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, true, false, WIDE, true>(A, sh, S, cost, b, lane, k, kk, live, kg, nullptr, nctl);
+                }
+            } else if (MODE != MODE_FUSED && nctl == kTU) {
+                pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg);
+            } else if (MODE != MODE_FUSED && nctl >= kPartialMin) {
+                pc_produce_batched<MODEL, MODE, R4Shared<MODEL>, false, false, false, true>(A, sh, S, cost, b, lane, k, kk, live, kg, nullptr, nctl);
             } else {
-                bool done = false;
-                if (MODE != MODE_FUSED && b * kTU + kTU <= H - 1)
-                    done = pc_produce_batched<MODEL, MODE>(A, sh, S, cost, b, lane, k, kk, live, kg);
-                if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
+                pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);   // (a short tail, or the final state only)
             }
             pc_publish(seq_ready, b + 1);
             if (b == 0) CCV_DIAG_STAMP(A, 5);

@@ -59,13 +59,19 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
     for (int b = 0; b < nblocks; ++b) {
         // ---------------- states and controls of steps 8b .. 8b+7
         bool done = false;
-        if (b * kTU + kTU <= H - 1) {
+        const int nctl = min(kTU, H - 1 - b * kTU);   // steps of this block that carry controls
+        if (nctl == kTU) {
             if (fast_clamp)
                 done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, true, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg);
             else if constexpr (!FB)   // (a second instantiation, so that a NaN in the warm start gives the multi-wave kernels'
                                       //  bits; full body has no registers for it -- its NaN case takes pc_produce below, whose
                                       //  sin / cos differ from the block path's in the last place)
                 done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, false, WIDE>(A, sh, S, cost, b, lane, k, kk, live, kg);
+        } else if (nctl >= kPartialMin) {   // the horizon's last block, partly filled (C4: 7 of its 8 steps)
+            if (fast_clamp)
+                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, true, WIDE, true>(A, sh, S, cost, b, lane, k, kk, live, kg, nullptr, nctl);
+            else if constexpr (!FB)
+                done = pc_produce_batched<MODEL, MODE, SoloShared<MODEL>, false, false, WIDE, true>(A, sh, S, cost, b, lane, k, kk, live, kg, nullptr, nctl);
         }
         if (!done) pc_produce<MODEL, MODE, false>(A, sh, S, cost, b, lane, k, kk, live, kg);
         // ---------------- their distance to the window
