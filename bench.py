@@ -40,17 +40,21 @@ def algorithmic_bytes(T, udim):
 
 
 def rollout_kernel_name(model, k_local, device):
-    """The kernel ccv_mppi_create selects (csrc/ccv_mppi_capi.hip): more blocks of 64 samples than four per CU -> one wave
-    per block (k_rollout_solo); else the four-wave kernel, or the two-wave one for full body."""
+    """The kernel ccv_mppi_create selects (csrc/ccv_mppi_capi.hip): more blocks of 64 samples than four (full body) / five per CU ->
+    one wave per block (k_rollout_solo); else the four-wave kernel -- full body: up to one block per CU, the two-wave kernel
+    (k_rollout_pc) beyond."""
     forced = os.environ.get("CCV_MPPI_KERNEL")
     if forced:
         return {"v1": "k_rollout_cost", "pc": "k_rollout_pc", "r3": "k_rollout_pc" if model == "full_body" else "k_rollout_r3",
-                "r4": "k_rollout_pc" if model == "full_body" else "k_rollout_r4", "solo": "k_rollout_solo"}.get(forced, forced)
+                "r4": "k_rollout_r4", "solo": "k_rollout_solo"}.get(forced, forced)
     import torch
     cus = torch.cuda.get_device_properties(device).multi_processor_count
-    if (k_local + 63) // 64 > (4 if model == "full_body" else 5) * cus:
+    blocks = (k_local + 63) // 64
+    if blocks > (4 if model == "full_body" else 5) * cus:
         return "k_rollout_solo"
-    return "k_rollout_pc" if model == "full_body" else "k_rollout_r4"
+    if model == "full_body" and blocks > cus:
+        return "k_rollout_pc"
+    return "k_rollout_r4"
 
 
 def device_copy_gbs(torch, nbytes=1 << 30, reps=10):
@@ -372,7 +376,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="C2", help="C2 (headline) | C3 | C4")
+    ap.add_argument("--workload", default="C2", help="C2 (headline) | C3 | C4 | dd_default | sd_default | fb_default (the reference's own "
+                                                     "operating points, K = 1 000 / 1 000 / 10 000 at H = 15: profiling, not a bench line)")
     ap.add_argument("--samples-per-gpu", type=int, default=None)
     ap.add_argument("--path", default=None, help="reference path instead of the workload's: straight | sinusoid | dkan")
     ap.add_argument("--dt", type=float, default=None,
@@ -425,7 +430,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    w = configs.workload(args.workload)
+    if args.workload.endswith("_default"):
+        w = {"dd_default": configs.Workload("dd_default", configs.diff_drive_defaults(1000, 15), "sinusoid", "diff_drive K=1000 T=15 sinusoid (code defaults)"),
+             "sd_default": configs.Workload("sd_default", configs.steering_defaults(1000, 15), "sinusoid", "steering_diff_drive K=1000 T=15 sinusoid (code defaults, launch K)"),
+             "fb_default": configs.Workload("fb_default", configs.full_body_defaults(10000, 15), "dkan", "full_body K=10000 T=15 dkan (code defaults)")}[args.workload]
+    else:
+        w = configs.workload(args.workload)
     if args.path:
         import dataclasses
         w = dataclasses.replace(w, path=args.path, description=w.description.replace(w.path, args.path))

@@ -258,7 +258,7 @@ void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const 
         launch_rollout_solo(model, h->wide_turn, at, A, W);
         return;
     }
-    if (model != CCV_MPPI_FULL_BODY && h->coop == 3) {   // four-wave kernel (mppi_rollout_r4.h)
+    if (h->coop == 3) {   // four-wave kernel (mppi_rollout_r4.h)
         launch_rollout_r4(model, mode, h->wide_turn, at, A, W);
         return;
     }
@@ -718,11 +718,19 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     h->lds_window = !(env && std::strcmp(env, "scalar") == 0);
     const char* kenv = getenv("CCV_MPPI_KERNEL");
     h->coop = !(kenv && std::strcmp(kenv, "v1") == 0) && h->lds_window;
+    int cus = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
     // diff-drive, steering: the four-wave kernel (noise / dynamics / distance / store wave, mppi_rollout_r4.h; round 2: -6 %
-    // against the three-wave kernel at C2 and, unlike it, the same time in every process at C3).  Full body keeps the
-    // two-wave kernel: its producer needs 250 VGPR (four waves per SIMD allow 128).
+    // against the three-wave kernel at C2 and, unlike it, the same time in every process at C3).  Full body: its dynamics batch
+    // needs 250 VGPRs, so the four-wave kernel is built for one wave per SIMD there, one workgroup per CU -- used up to that many
+    // blocks of 64 samples (round 3; the reference's own K = 10 000 is 157 blocks), the two-wave kernel up to four per CU.
     // CCV_MPPI_KERNEL=pc / r3 / r4 force one where built (experiments, tests)
     if (h->coop && h->cfg.model != CCV_MPPI_FULL_BODY) h->coop = 3;
+    if (h->coop && h->cfg.model == CCV_MPPI_FULL_BODY && h->nblocks <= cus) h->coop = 3;
+    if (h->coop && kenv && std::strcmp(kenv, "r4") == 0) h->coop = 3;
     if (h->coop && kenv && std::strcmp(kenv, "r3") == 0 && h->cfg.model != CCV_MPPI_FULL_BODY) h->coop = 2;
     if (h->coop && kenv && std::strcmp(kenv, "pc") == 0) h->coop = 1;
     // More blocks of 64 samples than the multi-wave kernels can hold at once (4 workgroups per CU): one wave does
@@ -731,9 +739,6 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     // diff drive K = 65 536: 45 vs 56; 98 304: 85 vs 80; 131 072: 106 vs 88; 524 288: 348 vs 295; steering 131 072: 135 vs
     // 117; full body 65 536: 169 vs 192; 98 304: 316 vs 291; 131 072 (C4): 374 vs 335.  CCV_MPPI_KERNEL=solo forces it.
     {
-        int cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         // (round 2, four-wave kernel against one-wave kernel, diff drive, kernel us: K = 81 920 61.0 vs 64.2; 98 304 66.0 vs 64.3;
         //  131 072 75.2 vs 71.0; 196 608 104 vs 99; steering 131 072 90.1 vs 84.0 -- the switch sits at five blocks per CU there)
         h->solo = h->coop && !kenv && h->nblocks > (h->cfg.model == CCV_MPPI_FULL_BODY ? 4 : 5) * cus;

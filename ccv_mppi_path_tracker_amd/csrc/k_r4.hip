@@ -1,4 +1,4 @@
-// translation unit: the four-wave rollout kernel (mppi_rollout_r4.h), diff drive and steering
+// translation unit: the four-wave rollout kernel (mppi_rollout_r4.h), diff drive and steering (full body: k_r4_fb.hip)
 #include "mppi_launch.h"
 #include "mppi_rollout_r4.h"
 
@@ -22,9 +22,12 @@ static void launch_r4_model(int mode, bool wide, const LaunchAt& at, const Rollo
     else launch_at(k_rollout_r4<MODEL, MODE_COST>, grid, block, at, A, W);
 }
 
+void launch_rollout_r4_fb(int mode, const LaunchAt& at, const RolloutArgs& A, const Window& W);   // k_r4_fb.hip
+
 void launch_rollout_r4(int model, int mode, bool wide, const LaunchAt& at, const RolloutArgs& A, const Window& W) {
     if (model == CCV_MPPI_DIFF_DRIVE) launch_r4_model<CCV_MPPI_DIFF_DRIVE>(mode, wide, at, A, W);
-    else launch_r4_model<CCV_MPPI_STEERING_DIFF_DRIVE>(mode, false, at, A, W);
+    else if (model == CCV_MPPI_STEERING_DIFF_DRIVE) launch_r4_model<CCV_MPPI_STEERING_DIFF_DRIVE>(mode, false, at, A, W);
+    else launch_rollout_r4_fb(mode, at, A, W);
 }
 
 }  // namespace ccv

@@ -1,5 +1,5 @@
 // Launchers of the rollout kernel families.  Every family is a translation unit of its own (k_r4.hip, k_r3.hip, k_pc.hip,
-// k_pc_fb.hip, k_solo.hip, k_solo_fb.hip, k_plain.hip): hipcc spends over a minute on all instantiations in one file, the
+// k_r4_fb.hip, k_pc_fb.hip, k_solo.hip, k_solo_fb.hip, k_plain.hip): hipcc spends over a minute on all instantiations in one file, the
 // units compile side by side (build.py).  ccv_mppi_capi.hip -- the C ABI -- selects the family and calls these.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -17,7 +17,7 @@ struct LaunchAt {
 };
 
 // mode: MODE_FUSED / MODE_ROLLOUT / MODE_COST (mppi_rollout_pc.h).  K, H, ... come from the arguments themselves.
-void launch_rollout_r4(int model, int mode, bool wide, const LaunchAt& at, const RolloutArgs& A, const Window& W);   // dd, sd
+void launch_rollout_r4(int model, int mode, bool wide, const LaunchAt& at, const RolloutArgs& A, const Window& W);   // all models
 void launch_rollout_r3(int model, int mode, const LaunchAt& at, const RolloutArgs& A, const Window& W);              // dd, sd
 void launch_rollout_pc(int model, int mode, const LaunchAt& at, const RolloutArgs& A, const Window& W);              // all models
 void launch_rollout_solo(int model, bool wide, const LaunchAt& at, const RolloutArgs& A, const Window& W);           // fused only

@@ -24,7 +24,10 @@
 namespace ccv {
 
 constexpr int kR4Waves = 4;
-constexpr int kR4RB = 12;   // rows per LDS transpose batch in the epilogue (6: +1.4 us at C2)
+// rows per LDS transpose batch in the epilogue: a multiple of u_dim that fits the loop's buffers (12 at u_dim 2 and 3; 6: +1.4 us
+// at C2), 15 for full body
+template <int MODEL>
+constexpr int kR4RB = MODEL == CCV_MPPI_FULL_BODY ? 15 : 12;
 
 // The control rows of the epilogue, dealt to the four waves as contiguous ranges (first row a multiple of u_dim, so that a
 // row's control dimension is a compile-time function of its position in the range: pc_reduce_rows).
@@ -99,10 +102,14 @@ __device__ __forceinline__ void r4_noise_block(const RolloutArgs& A, SH& sh, con
     using std::integral_constant;
     if constexpr (NCALL == 4) {
         group(integral_constant<int, 0>{}, integral_constant<int, 4>{});
-    } else {
-        static_assert(NCALL == 6, "steering: 3 + 3 Philox calls");
+    } else if constexpr (NCALL == 6) {
         group(integral_constant<int, 0>{}, integral_constant<int, 3>{});
         group(integral_constant<int, 3>{}, integral_constant<int, 3>{});
+    } else {
+        static_assert(NCALL == 10, "full body: 4 + 3 + 3 Philox calls");
+        group(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+        group(integral_constant<int, 4>{}, integral_constant<int, 3>{});
+        group(integral_constant<int, 7>{}, integral_constant<int, 3>{});
     }
 }
 
@@ -208,16 +215,19 @@ __device__ __forceinline__ R4Lane r4_lane(const RolloutArgs& A) {
 // TAIL (fused iteration): the horizon's last block carries kPartialMin .. 7 control steps and is made as a masked batch
 // (pc_produce_batched, PARTIAL) -- an instantiation of its own, chosen by the launcher from H: with the masked producer merely
 // present in the dynamics wave's loop, the kernel that never runs it (C2: H - 1 = 6 * 8 + 1) was 1.3 us slower.
+// Full body (round 3): the same four roles with one wave per SIMD -- its dynamics batch needs 250 registers and spills some thirty
+// at a 256 cap; alone on its SIMD a wave may have 512 -- i.e. one workgroup per CU: the kernel for K up to one block of 64
+// samples per CU, where the reference's own operating point lies (K = 10 000: 157 blocks on 256 CUs; in the two-wave kernel every
+// wave was alone on its SIMD there too, and its producer made the 40 normals of a block itself).
 template <int MODEL, int MODE, bool WIDE = false, bool TAIL = false>
-__global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutArgs Ak, const Window Wk) {
+__global__ __launch_bounds__(kR4Waves * 64, MODEL == CCV_MPPI_FULL_BODY ? 1 : 4) void k_rollout_r4(const RolloutArgs Ak, const Window Wk) {
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     constexpr bool COST = MODE != MODE_ROLLOUT;
     constexpr int UD = udim_of(MODEL);
-    static_assert(!FB, "diff drive and steering only");
     static_assert(!WIDE || (MODEL == CCV_MPPI_DIFF_DRIVE && MODE == MODE_FUSED), "the wide-turn form exists for the fused diff-drive iteration");
     static_assert(!TAIL || MODE == MODE_FUSED, "the stage-wise modes carry the masked producer anyway");
     __shared__ R4Shared<MODEL> sh;
-    static_assert(offsetof(R4Shared<MODEL>, zs) + sizeof(sh.zs) >= kR4Waves * kR4RB * (kPcSamples + 2) * sizeof(double), "epilogue buffers");
+    static_assert(offsetof(R4Shared<MODEL>, zs) + sizeof(sh.zs) >= kR4Waves * kR4RB<MODEL> * (kPcSamples + 2) * sizeof(double), "epilogue buffers");
     touch_rollout_args();
     const RolloutArgs A = with_resident_pose(Ak);
     // The prologue runs in all sixteen waves of a CU at once and SIMD arbitration is oldest first: the workgroup dispatched last
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wv == 0) CCV_DIAG_STAMP(A, 0);
     const int nblocks = (H + kTU - 1) / kTU;
-    const int nstates = H;   // states that reach the path cost (dd:199)
+    const int nstates = FB ? H - 2 : H;   // states that reach the path cost (dd:199 / fb:409)
     // blocks whose controls are made as a batch: their normals come from the noise wave -- all eight steps' worth, also for a
     // last block that uses fewer but at least kPartialMin (pc_produce_batched, PARTIAL); a shorter tail is the dynamics wave's
     // own, step by step (pc_produce)
@@ -329,6 +339,7 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         const bool live = L.live;
         const uint32_t kg = L.kg;
         double cost = 0.0;
+        if constexpr (FB && COST) cost += A.w_yaw * (A.x0[2] - A.yaw_ref0) * (A.x0[2] - A.yaw_ref0);   // fb:408
         for (int b = 0; b < nblocks; ++b) {
             r4_rotate_priority(A, b, 1);
             if (b >= 2) {   // the buffers of block b last held block b-2: both readers must have taken it
@@ -485,8 +496,8 @@ __global__ __launch_bounds__(kR4Waves * 64, 4) void k_rollout_r4(const RolloutAr
         if (wv == 0) CCV_DIAG_STAMP_VALUE(A, 9, wgt);
         if (wv == 2) CCV_DIAG_STAMP_VALUE(A, 11, wgt);
         if (A.fuse_update) {
-            double* buf = &sh.p[0][0][0][0] + wv * (kR4RB * (kPcSamples + 2));
-            pc_reduce_rows<kR4RB, MODEL, true>(A, sh, buf, upd, rows, mcount, wgt, lane, kk, fast_clamp);
+            double* buf = &sh.p[0][0][0][0] + wv * (kR4RB<MODEL> * (kPcSamples + 2));
+            pc_reduce_rows<kR4RB<MODEL>, MODEL, true>(A, sh, buf, upd, rows, mcount, wgt, lane, kk, fast_clamp);
             if (wv == kR4Waves - 1) pc_block_stats(A, R, wgt, total, live, lane);   // (the wave with the fewest rows)
         }
         if (wv == 0) CCV_DIAG_STAMP(A, 10);

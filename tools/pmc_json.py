@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_<workload>_pmc.json from the rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of tools/profile_r02.sh: HBM
+"""profiles/<tag>_<workload>_pmc.json from the rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of tools/profile_r03.sh: HBM
 bytes per launch of the rollout kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950
 (WRITE_SIZE exact; FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streams: doubled).  bench.py reads the
 latest of these for `roofline.traffic`.  usage: python tools/pmc_json.py <gpurun_out/tag dir> <tag>"""
@@ -32,7 +32,7 @@ for w in ("C2", "C3", "C4"):
          "correction": "gfx950: WRITE_SIZE exact, FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md "
                        "'FETCH_SIZE reports exactly 1/2'; calibrated for this code's 8-byte-per-lane pattern with tools/microbench/hbm_calib.hip): doubled",
          "hbm_bytes_per_launch": int((wr + 2 * fe) * 1024), "algorithmic_bytes_per_launch": ALG[w],
-         "command": "tools/profile_r02.sh %s: rocprofv3 --pmc WRITE_SIZE (and, in its own run, --pmc FETCH_SIZE) --output-format csv -- python3 bench.py "
-                    "--workload %s --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-events --no-closed-loop-leg" % (tag, w)}
+         "command": "tools/profile_r03.sh %s: rocprofv3 --pmc WRITE_SIZE (and, in its own run, --pmc FETCH_SIZE) --output-format csv -- python3 bench.py "
+                    "--workload %s --steps 40 --warmup 5 --no-cpu-baseline --no-other-workloads --no-defaults-leg --no-kernel-events --no-closed-loop-leg" % (tag, w)}
     json.dump(d, open(os.path.join(out_dir, "%s_pmc.json" % w), "w"), indent=1)
     print(w, d["hbm_bytes_per_launch"], "vs algorithmic", ALG[w], "ratio %.3f" % (d["hbm_bytes_per_launch"] / ALG[w]))

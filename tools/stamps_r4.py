@@ -24,9 +24,18 @@ else:
 p = w.params
 inputs = bench.script_inputs(amd, w, 64)
 g = amd.MPPIController(p)
-for it in range(2000):
-    s, xr, yr, yaw0 = inputs[it % len(inputs)]
-    g.iterate_enqueue(s, p.dt, xr, yr, yaw0, 42, it)
+if os.environ.get("STAMP_RESIDENT"):   # the device-resident closed loop (pose and window from the frame in HBM)
+    px, py = amd.make_path(w.path, p.resolution, length=400.0)
+    s0 = np.zeros(p.nstate)
+    s0[0], s0[1] = px[0], py[0]
+    g.resident_set_path(px, py)
+    g.resident_set_pose(s0)
+    for it in range(1500):
+        g.resident_step_enqueue(p.dt, 42, it, advance=it > 0)
+else:
+    for it in range(2000):
+        s, xr, yr, yaw0 = inputs[it % len(inputs)]
+        g.iterate_enqueue(s, p.dt, xr, yr, yaw0, 42, it)
 g.synchronize()
 NS = 16
 nb = min(4096, (p.num_samples + 63) // 64)
