@@ -304,6 +304,15 @@ __global__ __launch_bounds__(kR4Waves * 64, MODEL == CCV_MPPI_FULL_BODY ? 1 : 4)
     R4Rows rows = r4_rows<UD>(H, nblocks, wv, nb_early);
     if (!(COST && A.fuse_update)) rows.n = 0;
     UpdT<MODE> upd[kUpdCH];
+    // Preconditions of the early re-read (noise and dynamics wave, before the kernel's barrier): the rows were stored by ANOTHER
+    // wave of this workgroup; they are visible to this wave's loads because (1) the store wave has waited for their
+    // acknowledgement (counted vmcnt) before it raised seq_stored, (2) all waves of a workgroup share one CU's vector L1, which
+    // is write-through, and none of these rows has been loaded by this CU before (nothing stale can sit in L1).  (2) does not
+    // hold in threadgroup-split mode (tgsplit: a workgroup's waves on different CUs): the kernel must not be built or launched
+    // with -mtgsplit / amdgpu-tgsplit.  hipcc's default is off, and the build (build.py) does not set it.
+    // Controls are re-derived from the normals with the clamp form of the launch (fast_clamp: v_max / v_min); the rows of a
+    // step-by-step tail (pc_produce: compare-and-select) can differ from that in ONE way -- the sign of a zero at a bound of
+    // +-0 -- which no sum, cost or comparison can see (clampd_fast, mppi_kernels.h).
     auto early_fetch = [&]() {
         if constexpr (MODE == MODE_FUSED) {   // (stage-wise cost call: fp64 controls, 120 registers -- fetched after the barrier)
             if (rows.n > 0) {

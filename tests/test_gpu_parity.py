@@ -303,6 +303,48 @@ def test_one_wave_kernel_agrees_with_the_multi_wave_kernels(monkeypatch, wl, K, 
     np.testing.assert_allclose(ub, uo, rtol=TOL_U, atol=1e-12)
 
 
+@pytest.mark.parametrize("K,H", [(10000, 15), (256, 80), (1000, 23), (130, 9), (64, 3), (777, 128), (2049, 12)])
+def test_full_body_four_wave_kernel_agrees_with_the_two_wave_kernel(monkeypatch, K, H):
+    """Round 3: full body up to one block of 64 samples per CU -- the reference's own operating point, K = 10 000, H = 15 --
+    runs the four-wave kernel (mppi_rollout_r4.h, one wave per SIMD); beyond, the two-wave kernel (mppi_rollout_pc.h).  The
+    same building blocks: the same samples and states bit for bit, costs and controls equal up to the order in which the
+    waves' cost parts and the rows' partial sums are added; both equal to the oracle.  Horizons with a full-block tail, a
+    masked partial tail (7, 6 steps), a short tail taken step by step (3 steps) and shorter than one block."""
+    p = configs.workload("C4").params.with_(num_samples=K, horizon=H)
+    path = helpers.oracle_path("dkan")
+    state = start_state(p, path)
+    xr, yr, yaw = helpers.oracle_window(p, path, state)
+    monkeypatch.delenv("CCV_MPPI_KERNEL", raising=False)
+    a = MPPIController(p)               # default: the four-wave kernel at these sizes
+    monkeypatch.setenv("CCV_MPPI_KERNEL", "pc")
+    b = MPPIController(p)
+    monkeypatch.setenv("CCV_MPPI_KERNEL", "r4")
+    c = MPPIController(p)               # forced: the same kernel as the default must have been
+    for it in range(2):
+        ua, ub, uc = (g.iterate(state, p.dt, xr, yr, yaw[0], 5, it, want_stats=False) for g in (a, b, c))
+        np.testing.assert_array_equal(ua, uc)
+        np.testing.assert_allclose(ua, ub, rtol=1e-10, atol=1e-13)
+        if it == 0:
+            np.testing.assert_array_equal(a.read_controls(), b.read_controls())
+            np.testing.assert_array_equal(a.read_candidates(), b.read_candidates())
+            np.testing.assert_allclose(a.read_costs(), b.read_costs(), rtol=1e-12)
+    np.testing.assert_array_equal(a.read_costs(), c.read_costs())
+    o = helpers.oracle_for(p, min(K, 2048))
+    kcmp = min(K, 2048)
+    for it in range(2):
+        if it == 1:
+            o.set_nominal(ua_first)
+        o.iterate(state, p.dt, xr, yr, yaw[0], seed=5, rng="philox", iteration=it)
+        if it == 0:
+            # (the oracle only rolls the first 2 048 samples at the large K: their costs and controls; u* from the device)
+            h = MPPIController(p)
+            ua_first = h.iterate(state, p.dt, xr, yr, yaw[0], 5, 0, want_stats=False)
+            np.testing.assert_array_equal(h.read_controls(0, kcmp), o.get_controls())
+            assert np.max(np.abs(h.read_costs(0, kcmp) - o.costs()) / o.costs()) < TOL_COST
+    np.testing.assert_array_equal(a.read_controls(0, kcmp), o.get_controls())
+    assert np.max(np.abs(a.read_costs(0, kcmp) - o.costs()) / o.costs()) < TOL_COST
+
+
 # --------------------------------------------------------------------------------------------------------------
 # edge cases
 # --------------------------------------------------------------------------------------------------------------
