@@ -45,7 +45,7 @@ struct R4Rows {
 template <int UD>
 __device__ __forceinline__ R4Rows r4_rows(const int H, const int nblocks, const int wv, int& nb_early) {
     const int R = (H - 1) * UD;
-    nb_early = max(0, nblocks - 3);   // (2: +0.8 us, 4: +0.3 us at C2)
+    nb_early = max(0, nblocks - 3);   // (round 2: 2: +0.8 us, 4: +0.3 us at C2; round 3, after the layout fix: 2: +0.4, 4: +-0.1)
     const int r_early = min(R, nb_early * kTU * UD);
     const int half_e = ((r_early / UD + 1) / 2) * UD, half_l = (((R - r_early) / UD + 1) / 2) * UD;
     switch (wv) {
