@@ -78,6 +78,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, jobs=None):
     with ThreadPoolExecutor(jobs) as pool:
         list(pool.map(lambda c: _run(c, verbose), cmds))
     _run([cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", target] + objs, verbose)
+    shutil.rmtree(objdir, ignore_errors=True)   # (every build compiles everything: the objects are of no further use)
     return target
 
 

@@ -46,6 +46,14 @@ template <int UD>
 __device__ __forceinline__ R4Rows r4_rows(const int H, const int nblocks, const int wv, int& nb_early) {
     const int R = (H - 1) * UD;
     nb_early = max(0, nblocks - 3);   // (round 2: 2: +0.8 us, 4: +0.3 us at C2; round 3, after the layout fix: 2: +0.4, 4: +-0.1)
+    if (nb_early == 0) {
+        // a horizon of three blocks or fewer (the reference default H = 15 is two): no row can be re-read early, so all of
+        // them are dealt to ALL FOUR waves and read after the barrier -- with the early / late split the noise and the
+        // dynamics wave had nothing and the other two a batch more each (H = 15: 14 + 14 rows in 2 batches -> 8 + 8 + 8 + 4 in 1)
+        const int per = ((R / UD + kR4Waves - 1) / kR4Waves) * UD;
+        const int first = min(R, wv * per);
+        return R4Rows{first, min(per, R - first)};
+    }
     const int r_early = min(R, nb_early * kTU * UD);
     const int half_e = ((r_early / UD + 1) / 2) * UD, half_l = (((R - r_early) / UD + 1) / 2) * UD;
     switch (wv) {
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(kR4Waves * 64, MODEL == CCV_MPPI_FULL_BODY ? 1 : 4)
     // +-0 -- which no sum, cost or comparison can see (clampd_fast, mppi_kernels.h).
     auto early_fetch = [&]() {
         if constexpr (MODE == MODE_FUSED) {   // (stage-wise cost call: fp64 controls, 120 registers -- fetched after the barrier)
-            if (rows.n > 0) {
+            if (rows.n > 0 && nb_early > 0) {   // (nb_early == 0: every wave reads its rows after the barrier)
                 pc_wait_for(seq_stored, nb_early);   // the rows are in HBM / L2
                 r4_fetch0(A, upd, rows, r4_lane(A).kk);
             }
@@ -495,7 +503,7 @@ __global__ __launch_bounds__(kR4Waves * 64, MODEL == CCV_MPPI_FULL_BODY ? 1 : 4)
         // the cost parts are in LDS, and p / ab / c / zs are dead
         pc_barrier_lds();
         if (wv == 0) CCV_DIAG_STAMP(A, 8);
-        if ((MODE != MODE_FUSED || wv >= 2) && mcount > 0) r4_fetch0(A, upd, rows, kk);
+        if ((MODE != MODE_FUSED || wv >= 2 || nb_early == 0) && mcount > 0) r4_fetch0(A, upd, rows, kk);
         const double total = ((sh.cost[0][lane] + sh.cost[1][lane]) + sh.cost[2][lane]) + sh.cost[3][lane];
         const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
         if (wv == 0 && live) {
