@@ -503,7 +503,24 @@ __global__ __launch_bounds__(kR4Waves * 64, MODEL == CCV_MPPI_FULL_BODY ? 1 : 4)
         // the cost parts are in LDS, and p / ab / c / zs are dead
         pc_barrier_lds();
         if (wv == 0) CCV_DIAG_STAMP(A, 8);
-        if ((MODE != MODE_FUSED || wv >= 2 || nb_early == 0) && mcount > 0) r4_fetch0(A, upd, rows, kk);
+        // A horizon of one or two time blocks (the reference default H = 15): every normal of it is still in sh.zs -- block b in
+        // zs[b & 1] -- so the rows come from there instead of from memory (0.7 us of load latency on the epilogue's chain).  The
+        // transpose buffers overlap zs: every wave has its rows in registers before any of them is written (second barrier).
+        bool from_lds = false;
+        if constexpr (MODE == MODE_FUSED) {
+            from_lds = nblocks <= 2;
+            if (from_lds) {
+                constexpr int kMaxLdsRows = 4 * UD;   // (rows per wave there: at most ceil(15 / 4) steps' worth)
+                static_assert(kMaxLdsRows <= kUpdCH, "first chunk");
+#pragma unroll
+                for (int i = 0; i < kMaxLdsRows; ++i) {
+                    const int row = rows.first + min(i, max(mcount - 1, 0));
+                    upd[i] = sh.zs[(row / (kTU * UD)) & 1][row % (kTU * UD)][lane];
+                }
+                pc_barrier_lds();
+            }
+        }
+        if (!from_lds && (MODE != MODE_FUSED || wv >= 2 || nb_early == 0) && mcount > 0) r4_fetch0(A, upd, rows, kk);
         const double total = ((sh.cost[0][lane] + sh.cost[1][lane]) + sh.cost[2][lane]) + sh.cost[3][lane];
         const double wgt = live ? exp(-total / A.lambda) : 0.0;   // dd:219 (no min-cost shift)
         if (wv == 0 && live) {

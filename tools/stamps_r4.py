@@ -19,6 +19,8 @@ if wl == "dd1000":
     w = configs.Workload("dd1000", configs.diff_drive_defaults(1000, 15), "sinusoid", "diff_drive K=1000 T=15 sinusoid")
 elif wl == "sd1000":
     w = configs.Workload("sd1000", configs.steering_defaults(1000, 15), "sinusoid", "steering K=1000 T=15 sinusoid")
+elif wl == "fb10000":
+    w = configs.Workload("fb10000", configs.full_body_defaults(10000, 15), "dkan", "full body K=10000 T=15 dkan")
 else:
     w = configs.workload(wl)
 p = w.params
