@@ -81,6 +81,8 @@ def script_inputs(amd, w, n):
     px, py = amd.make_path(w.path)
     rng = np.random.default_rng(0)
     span = max(1, len(px) - 2 * p.horizon // 3)
+    if os.environ.get("CCV_BENCH_SCRIPT_SPAN"):   # diagnostic: only poses whose window does not run past the end of the path
+        span = max(1, min(span, int(os.environ["CCV_BENCH_SCRIPT_SPAN"])))
     out = []
     for i in range(n):
         j = int(i * p.v_ref * p.dt / p.resolution) % span
