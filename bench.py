@@ -195,6 +195,48 @@ def closed_loop_leg(amd, torch, ctl, w, seed, warm=64, ticks=512):
             "distance_travelled_m": float(np.hypot(np.diff(tr[:, 0]), np.diff(tr[:, 1])).sum())}
 
 
+def live_pmc_traffic(workload_name, timeout_s=150):
+    """HBM bytes per rollout-kernel launch, MEASURED for this run: two short child runs of this script under
+    `rocprofv3 --pmc` -- WRITE_SIZE and FETCH_SIZE, each in a pass of its own with nothing else (MI355X_MICROARCH.md, HBM:
+    FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2) -- averaged over the launches of the rollout kernel and corrected as that
+    guide prescribes for gfx950 (WRITE_SIZE exact, FETCH_SIZE counts the 128-byte requests of a coalesced stream as 64 bytes:
+    doubled; calibrated for this code's access pattern with tools/microbench/hbm_calib.hip).  Called before this process
+    touches the GPU (the children have it to themselves, and nothing is started from a process that holds a GPU context).
+    Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob as _glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    got = {}
+    for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+        d = tempfile.mkdtemp(prefix="ccv_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--workload", workload_name, "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-events",
+               "--no-closed-loop-leg", "--no-other-workloads", "--no-defaults-leg", "--no-live-traffic"]
+        try:
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+        except Exception as e:   # noqa: BLE001 -- a profiler that cannot run is not a reason to fail the bench
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "%s pass: %s" % (counter, e)
+        vals = []
+        for f in _glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "rollout" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    vals.append(float(r["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+        if res.returncode != 0 or not vals:
+            return None, "%s pass: rc %d, %d kernel rows" % (counter, res.returncode, len(vals))
+        got[counter] = (sum(vals) / len(vals), len(vals))
+    total = (got["WRITE_SIZE"][0] + 2.0 * got["FETCH_SIZE"][0]) * 1024.0
+    return total, {"WRITE_SIZE_KB": round(got["WRITE_SIZE"][0]), "FETCH_SIZE_KB_raw": round(got["FETCH_SIZE"][0]),
+                   "launches_averaged": [got["WRITE_SIZE"][1], got["FETCH_SIZE"][1]],
+                   "correction": "gfx950: WRITE_SIZE exact, FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM)"}
+
+
 def latest_pmc_traffic(workload_name):
     """HBM bytes per rollout-kernel launch from the committed rocprofv3 --pmc summary (profiles/*pmc*.json)."""
     best = None
@@ -396,12 +438,20 @@ def main():
     ap.add_argument("--no-closed-loop-leg", action="store_true", help="skip the device-resident closed-loop figure of the default line")
     ap.add_argument("--no-state-store", action="store_true", help="skip the KxH x,y buffer (not the headline)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC profile instead of two rocprofv3 --pmc child runs of this launch")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the C3 / C4 legs of the default line")
     ap.add_argument("--no-defaults-leg", action="store_true", help="skip the reference-default operating points (K = 1 000 / 10 000, H = 15)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    # roofline.traffic, measured for THIS run (the headline launch only; before anything here touches the GPU)
+    live_traffic, live_detail = None, "not the headline launch"
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_live_traffic and not args.closed_loop
+            and args.workload in ("C2", "C3", "C4") and args.samples_per_gpu is None and args.dt is None and args.path is None
+            and not args.no_state_store and not os.environ.get("CCV_MPPI_KERNEL")):
+        live_traffic, live_detail = live_pmc_traffic(args.workload)
 
     import torch
     import torch.distributed as dist
@@ -611,6 +661,12 @@ def main():
         # the committed PMC pass is of the workload's own launch (its K, its kernel): no figure for any other launch
         pmc_applies = world == 1 and k_local == w.params.num_samples and args.dt is None and not args.no_state_store
         traffic = latest_pmc_traffic(args.workload) if pmc_applies else None
+        traffic_source = ("rocprofv3 --pmc pass of the same workload and kernel, committed under profiles/ (not measured by this run%s)"
+                          % ("" if args.no_live_traffic else ": " + str(live_detail))) if traffic else None
+        if pmc_applies and live_traffic:
+            traffic = live_traffic
+            traffic_source = {"measured": "by this run: two child runs of this command under rocprofv3 --pmc, before the timed region",
+                              **live_detail}
         out = {
             # BASELINE.json's metric string; `value` is its first component, `ms_per_step` the second (ms per MPPI iteration)
             "metric": "trajectory rollouts/s (K\u00d7iters/s) + ms/MPPI-iteration, diff-drive T=50" if args.workload == "C2"
@@ -643,7 +699,7 @@ def main():
                          # re-derives the controls), i.e. measured_traffic_frac of the 8 TB/s -- what limits it is VALU issue
                          # (profiles/*_pmc_summary.txt: SQ_ACTIVE_INST_VALU), not HBM
                          "measured_traffic_frac": (traffic / roll_avg_s / 1e9 / HBM_PEAK_GBS) if (traffic and roll_avg_s > 0) else None,
-                         "traffic_source": "rocprofv3 --pmc pass of the same workload and kernel, committed under profiles/ (not measured by this run)" if traffic else None,
+                         "traffic_source": traffic_source,
                          "limiter": "valu-issue (contract bound: hbm)",
                          "kernel": rollout_kernel_name(p.model, k_local, local_rank) if args.dt is None else
                                    rollout_kernel_name(p.model, k_local, local_rank) + " (its full-range sin/cos instantiation beyond the small-turn gate)",

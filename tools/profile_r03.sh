@@ -9,7 +9,7 @@ T=${1:-r03a}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-other-workloads --no-defaults-leg"
+Q="--no-cpu-baseline --no-other-workloads --no-defaults-leg --no-live-traffic"
 python3 $R/bench.py > $O/c2_bench.json 2> $O/c2_bench.err
 python3 $R/bench.py --steps 20 --warmup 5 > $O/c2_bench_driver_args.json 2>> $O/c2_bench.err
 python3 $R/bench.py --samples-per-gpu 524288 --steps 60 --warmup 10 --no-cpu-baseline > $O/c2_K524288_bench.json 2>/dev/null
