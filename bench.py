@@ -195,7 +195,7 @@ def closed_loop_leg(amd, torch, ctl, w, seed, warm=64, ticks=512):
             "distance_travelled_m": float(np.hypot(np.diff(tr[:, 0]), np.diff(tr[:, 1])).sum())}
 
 
-def live_pmc_traffic(workload_name, timeout_s=150):
+def live_pmc_traffic(workload_name, timeout_s=60):
     """HBM bytes per rollout-kernel launch, MEASURED for this run: two short child runs of this script under
     `rocprofv3 --pmc` -- WRITE_SIZE and FETCH_SIZE, each in a pass of its own with nothing else (MI355X_MICROARCH.md, HBM:
     FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2) -- averaged over the launches of the rollout kernel and corrected as that
