@@ -16,7 +16,7 @@ import bench  # noqa: E402
 
 n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 ok = True
-for wl, K in (("C2", 65536), ("C3", 65536), ("C4", 32768), ("C2", 1000)):
+for wl, K in (("C2", 65536), ("C3", 65536), ("C4", 32768), ("C2", 1000), ("C4", 10000), ("C3", 1000)):
     w = configs.workload(wl, num_samples=K)
     p = w.params
     inputs = bench.script_inputs(amd, w, 64)
@@ -49,7 +49,10 @@ for wl, K in (("C2", 65536), ("C3", 65536), ("C4", 32768), ("C2", 1000)):
         os.environ.pop("CCV_MPPI_KERNEL", None)
     du = float(np.max(np.abs(pair[0][0] - pair[1][0])) / max(np.max(np.abs(pair[1][0])), 1e-300))
     dxy = float(np.max(np.abs(pair[0][1] - pair[1][1])))
-    cross = du < 1e-9 and dxy < 1e-9
+    # (full body with the C4 weights has an effective sample size of order one: there the map amplifies a rounding difference
+    #  by ~2.5 per iteration -- 2e-13 after one iteration, 2e-7 after 16, order one after 24: tools/soak_cross.py C4 10000 ...)
+    tol = 1e-5 if p.model == "full_body" else 1e-9
+    cross = du < tol and dxy < tol
     print("%s K=%d: %d iterations twice: bit-identical %s, finite %s; 16 iterations vs the two-wave kernel: u* rel %.1e, states abs %.1e" % (
         wl, K, n_it, same, finite, du, dxy))
     ok = ok and same and finite and cross
