@@ -261,7 +261,8 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
                 // ---- cost terms that do not need the window ----
                 if constexpr (COST) {
                     if constexpr (!FB) {
-                        cost += A.w_v * ((u[0] - A.v_ref) * (u[0] - A.v_ref));   // dd:204-206
+                        const double dv = u[0] - A.v_ref;
+                        cost = fma(A.w_v * dv, dv, cost);   // dd:204-206 (the arithmetic of pc_produce_batched)
                     } else {
                         if (t < H - 2) {                                          // fb:409
                             cost += A.w_v * (u[0] - A.v_ref) * (u[0] - A.v_ref);  // fb:413
@@ -297,8 +298,14 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
                     S.p_v = u[0];
                     S.p_rv = u[3];
                 }
-                S.x = S.x + u[0] * cs * dt;
-                S.y = S.y + u[0] * sn * dt;
+                if constexpr (FB) {
+                    S.x = S.x + u[0] * cs * dt;
+                    S.y = S.y + u[0] * sn * dt;
+                } else {   // (the arithmetic of pc_produce_batched)
+                    const double step = u[0] * dt;
+                    S.x = fma(step, cs, S.x);
+                    S.y = fma(step, sn, S.y);
+                }
                 S.yaw = S.yaw + u[1] * dt;
                 if constexpr (FB) {
                     S.roll = S.roll + u[3] * dt;
@@ -307,7 +314,8 @@ __device__ __forceinline__ void pc_produce(const RolloutArgs& A, SH& sh, PcState
             } else {
                 if constexpr (!FB && COST) {
                     // t == H-1: the reference reads control index H-1, one past the end (dd:199,204): defined as 0.0 (Q1)
-                    cost += A.w_v * ((0.0 - A.v_ref) * (0.0 - A.v_ref));
+                    const double dv = 0.0 - A.v_ref;
+                    cost = fma(A.w_v * dv, dv, cost);
                 }
             }
         }
@@ -572,13 +580,14 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
         if constexpr (!FB) {
 #pragma unroll
             for (int tt = 0; tt < kTU; ++tt) {
-                const double cv = A.w_v * ((u[tt][0] - A.v_ref) * (u[tt][0] - A.v_ref));   // dd:204-206
+                // dd:204-206: v_weight (v - v_ref)^2, the last factor riding on the addition
                 if constexpr (PARTIAL) {
                     // t == H-1: the reference reads control index H-1, one past the end (dd:199,204): defined as 0.0 (Q1)
-                    const double phantom = A.w_v * ((0.0 - A.v_ref) * (0.0 - A.v_ref));
-                    cost += tt < nctl ? cv : (tt == nctl ? phantom : 0.0);
+                    const double dv = (tt < nctl ? u[tt][0] : 0.0) - A.v_ref;
+                    cost = tt <= nctl ? fma(A.w_v * dv, dv, cost) : cost;
                 } else {
-                    cost += cv;
+                    const double dv = u[tt][0] - A.v_ref;
+                    cost = fma(A.w_v * dv, dv, cost);
                 }
             }
         } else {
@@ -630,8 +639,17 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
             sh.p[b & (SH::kPBuf - 1)][tt][0][lane] = x - A.x0[0];
             sh.p[b & (SH::kPBuf - 1)][tt][1][lane] = y - A.x0[1];
         }
-        x = x + u[tt][0] * cs[tt] * dt;
-        y = y + u[tt][0] * sn[tt] * dt;
+        if constexpr (FB) {
+            // (the full-body kernels keep the reference's form: the one-wave kernel sits at 256 registers, and every
+            //  rearrangement of this block tried so far -- fused products here or in the cost terms, weights switched instead
+            //  of 64-bit selects -- either spills or costs it 4 - 14 us of C4's 206, profiles/README.md round 3)
+            x = x + u[tt][0] * cs[tt] * dt;
+            y = y + u[tt][0] * sn[tt] * dt;
+        } else {
+            const double step = u[tt][0] * dt;   // dd:106-107: x + v cos(yaw) dt -- one product shared, the other fused
+            x = fma(step, cs[tt], x);
+            y = fma(step, sn[tt], y);
+        }
     }
     if constexpr (MODE != MODE_COST && !SH::kStage) {
         if (A.store_xy) {   // one wave-uniform branch for the 16 stores (padded rows: no `live` predicate, as above)
