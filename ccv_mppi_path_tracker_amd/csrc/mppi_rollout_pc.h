@@ -904,8 +904,18 @@ __device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, d
     for (int i = 0; i < NV; ++i) {
         // d^2 = |p|^2 + min_j(...), gate d <= 100 (dd:185), cost += path_weight*d*d (dd:206)
         double d2 = m[i] + fma(px[i], px[i], py[i] * py[i]);
-        d2 = d2 < 1.0e4 ? fmax(d2, 0.0) : 1.0e4;   // NaN -> gate value, as `distance < min_distance` (dd:189) is false for NaN
-        cost += A.w_path * d2;
+        if constexpr (MODEL == CCV_MPPI_FULL_BODY) {   // (kept as it was: the one-wave full-body kernel is at its register limit)
+            d2 = d2 < 1.0e4 ? fmax(d2, 0.0) : 1.0e4;   // NaN -> gate value, as `distance < min_distance` (dd:189) is false for NaN
+            cost += A.w_path * d2;
+        } else {
+            // the same value in two instructions instead of four (compare, max, two selects): min(d2, 1e4) first -- of a NaN
+            // and a number v_min_f64 returns the number (d2 is the result of arithmetic: never a signalling NaN), which is
+            // the gate value -- then max(., 0); and the weight rides on the addition
+            double g;
+            asm("v_min_f64 %0, %1, %2" : "=v"(g) : "v"(d2), "s"(1.0e4));
+            asm("v_max_f64 %0, %1, 0" : "=v"(d2) : "v"(g));
+            cost = fma(A.w_path, d2, cost);
+        }
     }
 }
 
