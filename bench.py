@@ -39,21 +39,19 @@ def algorithmic_bytes(T, udim):
     return whole, whole
 
 
-def rollout_kernel_name(model, k_local, device, horizon=0):
+def rollout_kernel_name(model, k_local, device):
     """The kernel ccv_mppi_create selects (csrc/ccv_mppi_capi.hip): more blocks of 64 samples than four (full body) / five per CU ->
     one wave per block (k_rollout_solo); else the four-wave kernel -- full body: up to one block per CU, the two-wave kernel
     (k_rollout_pc) beyond."""
     forced = os.environ.get("CCV_MPPI_KERNEL")
     if forced:
         return {"v1": "k_rollout_cost", "pc": "k_rollout_pc", "r3": "k_rollout_pc" if model == "full_body" else "k_rollout_r3",
-                "r4": "k_rollout_r4", "solo": "k_rollout_solo",
-                "d2": "k_rollout_d2" if model == "full_body" and (horizon - 1) % 8 >= 4 else "k_rollout_pc"}.get(forced, forced)
+                "r4": "k_rollout_r4", "solo": "k_rollout_solo"}.get(forced, forced)
     import torch
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     blocks = (k_local + 63) // 64
     if blocks > (4 if model == "full_body" else 5) * cus:
-        # full body: the dense two-wave kernel where the horizon's last time block is a batch (csrc/mppi_rollout_d2.h)
-        return "k_rollout_d2" if model == "full_body" and (horizon - 1) % 8 >= 4 else "k_rollout_solo"
+        return "k_rollout_solo"
     if model == "full_body" and blocks > cus:
         return "k_rollout_pc"
     return "k_rollout_r4"
@@ -295,7 +293,7 @@ def measure_workload(amd, torch, configs, name, steps, warmup, stream, device, p
     return {"workload": "%s: %s, u_dim=%d, launch parameters" % (w.name, w.description, p.udim),
             "value": p.num_samples * steps / el, "unit": "rollouts/s", "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * el / steps, "primed_iterations": n, "finite": finite,
-            "kernel": rollout_kernel_name(p.model, p.num_samples, device, p.horizon), "kernel_avg_us": k_us,
+            "kernel": rollout_kernel_name(p.model, p.num_samples, device), "kernel_avg_us": k_us,
             "kernel_launches_averaged": int(n_ev), "iteration_avg_us": iter_us / max(n_ev, 1),
             "algorithmic_bytes_per_launch": B * p.num_samples,
             "frac": B * p.num_samples / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us > 0 else None,
@@ -362,7 +360,7 @@ def defaults_leg(amd, device, with_cpu=True):
         ctl.close()
         res["rollout_kernel_us"] = r_us / max(n_ev, 1)
         res["device_iteration_us"] = i_us / max(n_ev, 1)
-        res["kernel"] = rollout_kernel_name(p.model, p.num_samples, device, p.horizon)
+        res["kernel"] = rollout_kernel_name(p.model, p.num_samples, device)
         if not with_cpu:
             out[key] = res
             continue
@@ -703,8 +701,8 @@ def main():
                          "measured_traffic_frac": (traffic / roll_avg_s / 1e9 / HBM_PEAK_GBS) if (traffic and roll_avg_s > 0) else None,
                          "traffic_source": traffic_source,
                          "limiter": "valu-issue (contract bound: hbm)",
-                         "kernel": rollout_kernel_name(p.model, k_local, local_rank, p.horizon) if args.dt is None else
-                                   rollout_kernel_name(p.model, k_local, local_rank, p.horizon) + " (its full-range sin/cos instantiation beyond the small-turn gate)",
+                         "kernel": rollout_kernel_name(p.model, k_local, local_rank) if args.dt is None else
+                                   rollout_kernel_name(p.model, k_local, local_rank) + " (its full-range sin/cos instantiation beyond the small-turn gate)",
                          "kernel_avg_us": 1e6 * roll_avg_s,
                          "kernel_launches_averaged": int(n_ev),
                          "algorithmic_bytes_per_launch": B_roll * k_local,

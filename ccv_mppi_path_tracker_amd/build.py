@@ -13,10 +13,10 @@ LIBDIR = os.path.join(_PKG, "lib")
 LIB = os.path.join(LIBDIR, "libccv_mppi_hip.so")
 # one translation unit per rollout kernel family (csrc/mppi_launch.h) + the C ABI + the host prologue + the node mirror: they
 # compile side by side
-KERNEL_UNITS = ["k_r4_fb.hip", "k_r4.hip", "k_r3.hip", "k_pc.hip", "k_pc_fb.hip", "k_solo.hip", "k_solo_fb.hip", "k_d2_fb.hip", "k_plain.hip"]
+KERNEL_UNITS = ["k_r4_fb.hip", "k_r4.hip", "k_r3.hip", "k_pc.hip", "k_pc_fb.hip", "k_solo.hip", "k_solo_fb.hip", "k_plain.hip"]
 SOURCES = KERNEL_UNITS + ["ccv_mppi_capi.hip", "ccv_mppi_host.cpp", os.path.join("host", "mppi_node.cpp")]
 HEADERS = ["mppi_kernels.h", "mppi_update.h", "mppi_launch.h", "mppi_rollout_pc.h", "mppi_rollout_r3.h", "mppi_rollout_r4.h",
-           "mppi_rollout_solo.h", "mppi_rollout_d2.h", "mppi_resident.h", "fast_trig.h", "noise_spec.h",
+           "mppi_rollout_solo.h", "mppi_resident.h", "fast_trig.h", "noise_spec.h",
            os.path.join("..", "..", "include", "ccv_mppi.h"), os.path.join("..", "..", "include", "ccv_mppi_host.h"),
            os.path.join("..", "..", "include", "ccv_mppi_node.hpp")]
 DEPS = SOURCES + HEADERS

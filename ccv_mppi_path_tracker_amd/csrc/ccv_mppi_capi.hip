@@ -107,7 +107,6 @@ struct ccv_mppi_handle {
     int lds_window = 1;
     int coop = 1;
     bool solo = false;   // fused iterations run k_rollout_solo (one wave per 64 samples) instead of coop's kernel
-    bool d2 = false;     // ... or, full body, k_rollout_d2 (two waves of 128 registers per 64 samples, mppi_rollout_d2.h) where it applies
     bool wide_turn = false;   // this launch: diff drive beyond |w|max dt = pi/4 -> the full-range sin / cos instantiation
     bool fast_clamp_allowed = true;   // clampd_fast (mppi_kernels.h) unless CCV_MPPI_FAST_CLAMP=0
     int prio_rotate = 0, cu_count = 256;   // pc_rotate_priority (mppi_rollout_pc.h)
@@ -254,12 +253,6 @@ void launch_rollout_model(const ccv_mppi_handle* h, const RolloutArgs& A, const 
     const int model = h->cfg.model;
     const bool timed = mode == MODE_FUSED && h->ev_kernel_start;
     const LaunchAt at{h->stream, timed ? h->ev_kernel_start : nullptr, timed ? h->ev_kernel_stop : nullptr};
-    if (h->d2 && h->coop && mode == MODE_FUSED && !A.pending_vec) {
-        // full body, many blocks per CU: two waves per 64 samples, four waves per SIMD (mppi_rollout_d2.h).  (A deferred
-        // division pending -- K sharded over devices -- takes the kernel below, which divides while it stages the warm start.)
-        launch_rollout_d2_fb(at, A, W);
-        return;
-    }
     if (h->solo && h->coop && mode == MODE_FUSED) {
         // one wave per 64 samples (mppi_rollout_solo.h): K provides two or more such waves per SIMD
         launch_rollout_solo(model, h->wide_turn, at, A, W);
@@ -750,11 +743,6 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
         //  131 072 75.2 vs 71.0; 196 608 104 vs 99; steering 131 072 90.1 vs 84.0 -- the switch sits at five blocks per CU there)
         h->solo = h->coop && !kenv && h->nblocks > (h->cfg.model == CCV_MPPI_FULL_BODY ? 4 : 5) * cus;
         if (h->coop && kenv && std::strcmp(kenv, "solo") == 0) h->solo = true;
-        // full body beyond four blocks per CU: the dense two-wave kernel, for horizons whose last time block is a batch (its
-        // dynamics have no step-by-step form); CCV_MPPI_KERNEL=d2 forces it where it applies (with the one-wave kernel behind it)
-        const bool d2_applies = h->coop && h->cfg.model == CCV_MPPI_FULL_BODY && (h->H - 1) % kTU >= kPartialMin;
-        h->d2 = d2_applies && (kenv ? std::strcmp(kenv, "d2") == 0 : h->solo);
-        if (h->d2) h->solo = true;
     }
     // wave priorities (pc_rotate_priority): measured -4 us on the three-wave kernel (C2), -3 % on the two-wave one (C4), and
     // with four levels -5 us on the four-wave kernel (43.4 -> 38.3 us at C2)

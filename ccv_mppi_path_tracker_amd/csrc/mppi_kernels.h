@@ -40,7 +40,6 @@ namespace ccv {
 
 constexpr int kMaxH = CCV_MPPI_MAX_HORIZON;
 constexpr int kTU = 8;        // time steps per register block (kTU*u_dim is a multiple of 4 normals for every model)
-constexpr int kPartialMin = 4;   // a last block of at least this many control steps is made as a masked batch (pc_produce_batched, PARTIAL)
 constexpr int kBlock = 256;   // 4 waves: one per SIMD of a CU
 constexpr int kChunk = 2048;  // samples per k_update_partials block
 constexpr int kPcSamples = 64;   // samples per block of the cooperative kernels: one per lane (mppi_rollout_*.h)

@@ -21,7 +21,6 @@ void launch_rollout_r4(int model, int mode, bool wide, const LaunchAt& at, const
 void launch_rollout_r3(int model, int mode, const LaunchAt& at, const RolloutArgs& A, const Window& W);              // dd, sd
 void launch_rollout_pc(int model, int mode, const LaunchAt& at, const RolloutArgs& A, const Window& W);              // all models
 void launch_rollout_solo(int model, bool wide, const LaunchAt& at, const RolloutArgs& A, const Window& W);           // fused only
-void launch_rollout_d2_fb(const LaunchAt& at, const RolloutArgs& A, const Window& W);                                // full body, fused
 // the plain one-sample-per-lane kernel: philox = device noise (fused iteration) or controls read from the buffer
 void launch_rollout_plain(int model, bool philox, bool lds_window, const LaunchAt& at, const RolloutArgs& A, const Window& W);
 void launch_sample(int model, hipStream_t stream, const RolloutArgs& A);

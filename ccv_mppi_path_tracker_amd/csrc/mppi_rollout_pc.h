@@ -38,7 +38,6 @@ struct PcState {
     double roll, pitch;                                 // full body only
     double p_v, p_rv, p_sdir, p_cdir, p_c2, p_c3, p_ac;  // full body: step t-1 quantities for the ZMP term (fb:468-486)
     double sn, cs;                                      // diff drive: sin / cos of yaw, advanced by rotation (pc_produce_batched)
-    double r_sy, r_cy, r_sr, r_cr, r_sp, r_cp;          // full body, k_rollout_d2: the rotation chains between the halves of a block
 };
 template <int MODEL>
 constexpr int kPcStateWords = MODEL == CCV_MPPI_FULL_BODY ? 12 : (MODEL == CCV_MPPI_DIFF_DRIVE ? 5 : 3);
@@ -384,7 +383,7 @@ __device__ __forceinline__ void pc_noise_ahead(const RolloutArgs& A, float (*slo
 // chains (Philox -> Box-Muller -> sin/cos -> position, one step after the other) a lone wave waits out one by one.
 // (worth it from kPartialMin steps on: a block of one or two steps is quicker step by step than as a batch of eight -- C2's
 //  H - 1 = 49 leaves one step, and batching it cost the four-wave kernel 1.6 us)
-// (kPartialMin = 4: mppi_kernels.h)
+constexpr int kPartialMin = 4;
 template <int MODEL, int MODE, class SH, bool ZLDS = false, bool FASTCLAMP = false, bool WIDE = false, bool PARTIAL = false>
 __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh, PcState<MODEL>& S, double& cost,
                                                    const int b, const int lane, const int k, const int kk, const bool live,
@@ -785,14 +784,29 @@ __device__ __forceinline__ void pc_prune_window(const RolloutArgs& A, const SH& 
 // ---------------------------------------------------------------------------------------------------------------
 // LEAN (four-wave kernel, 128 VGPRs): two window points per register set instead of four and the running minimum taken
 // point pair by point pair -- 48 registers less; the same minima, hence the same bits.
-// pc_consume_at: the positions (relative to the pose) are in the caller's registers; pc_consume reads them from sh.p first.
 template <int NV, int MODEL, class SH, bool LEAN = false>
-__device__ __forceinline__ void pc_consume_at(const RolloutArgs& A, const SH& sh, double& cost, const double (&px)[NV],
-                                              const double (&py)[NV], const int lane, int* prune_on = nullptr) {
+__device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, double& cost, const int b, const int lane,
+                                           const int i0 = 0,          // states i0 .. i0+NV-1 of block b
+                                           int* prune_on = nullptr,   // wave-uniform switch of the window pruning (below)
+                                           int* taken_flag = nullptr, const int taken_value = 0) {   // see below
     const int H4 = (A.H + 3) & ~3;   // the window is padded with c = +inf: four points per iteration, no remainder
-    double m[NV];
+    double px[NV], py[NV], m[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) m[i] = INFINITY;
+    for (int i = 0; i < NV; ++i) {
+        px[i] = sh.p[b & (SH::kPBuf - 1)][i0 + i][0][lane];
+        py[i] = sh.p[b & (SH::kPBuf - 1)][i0 + i][1][lane];
+        if constexpr (SH::kStage) {   // staged positions are absolute
+            px[i] -= A.x0[0];
+            py[i] -= A.x0[1];
+        }
+        m[i] = INFINITY;
+    }
+    if (taken_flag) {
+        // three-wave kernel: the positions of the block are in registers -- tell the producer that the LDS buffer is free
+        // (mppi_rollout_r3.h).  The wait makes sure the loads above have returned before the number is written.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pc_publish(taken_flag, taken_value);
+    }
     // software pipeline: the coefficients of points j+4..j+7 are read from LDS (broadcast reads) before the ~100 fp64
     // instructions on points j..j+3 issue, so no iteration waits out the LDS latency.  sh.ab / sh.c carry 4 spare
     // entries past H4, so the last iteration's read-ahead stays inside the arrays.
@@ -903,30 +917,6 @@ __device__ __forceinline__ void pc_consume_at(const RolloutArgs& A, const SH& sh
             cost = fma(A.w_path, d2, cost);
         }
     }
-}
-
-template <int NV, int MODEL, class SH, bool LEAN = false>
-__device__ __forceinline__ void pc_consume(const RolloutArgs& A, const SH& sh, double& cost, const int b, const int lane,
-                                           const int i0 = 0,          // states i0 .. i0+NV-1 of block b
-                                           int* prune_on = nullptr,   // wave-uniform switch of the window pruning (pc_prune_window)
-                                           int* taken_flag = nullptr, const int taken_value = 0) {   // see below
-    double px[NV], py[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        px[i] = sh.p[b & (SH::kPBuf - 1)][i0 + i][0][lane];
-        py[i] = sh.p[b & (SH::kPBuf - 1)][i0 + i][1][lane];
-        if constexpr (SH::kStage) {   // staged positions are absolute
-            px[i] -= A.x0[0];
-            py[i] -= A.x0[1];
-        }
-    }
-    if (taken_flag) {
-        // three-wave kernel: the positions of the block are in registers -- tell the producer that the LDS buffer is free
-        // (mppi_rollout_r3.h).  The wait makes sure the loads above have returned before the number is written.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        pc_publish(taken_flag, taken_value);
-    }
-    pc_consume_at<NV, MODEL, SH, LEAN>(A, sh, cost, px, py, lane, prune_on);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
