@@ -434,7 +434,12 @@ void FullBodyStateEstimator::get_CurrentState(double dt_) {
     current_state_.yaw = gazebo_pose_[2];
     current_state_.roll = imu_roll_;     // fb:552-553
     current_state_.pitch = imu_pitch_;
-    const double CoM[3] = {base2CoM * std::sin(imu_pitch_), -base2CoM * std::sin(imu_roll_), base2CoM * std::cos(imu_pitch_) * std::cos(imu_roll_)};
+    // (sin and cos of one angle through one sincos call, as the oracle's restatement: glibc's sincos and its sin / cos differ in
+    //  the last place now and then, and which of them a compiler emits for std::sin(a), std::cos(a) is its own choice)
+    double s_pitch, c_pitch, s_roll, c_roll;
+    ::sincos(imu_pitch_, &s_pitch, &c_pitch);
+    ::sincos(imu_roll_, &s_roll, &c_roll);
+    const double CoM[3] = {base2CoM * s_pitch, -base2CoM * s_roll, base2CoM * c_pitch * c_roll};
     const double accel[3] = {accel_x, accel_y, 0.0};
     double H_G[3], H_Gdot[3], zmp[3];
     for (int k = 0; k < 3; ++k) {

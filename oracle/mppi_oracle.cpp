@@ -407,7 +407,13 @@ struct FbEstimator {
         state[2] = yaw;
         state[3] = imu_roll;
         state[4] = imu_pitch;
-        const V3 CoM{base2CoM * std::sin(imu_pitch), -base2CoM * std::sin(imu_roll), base2CoM * std::cos(imu_pitch) * std::cos(imu_roll)};
+        // sin and cos of one angle through ONE libm call, written out: g++ merges std::sin(a) / std::cos(a) into sincos(a) by
+        // itself, clang (the host mirror's compiler) does not, and glibc's sincos differs from its sin / cos in the last place
+        // about once in 300 arguments -- both sides call it explicitly
+        double s_pitch, c_pitch, s_roll, c_roll;
+        ::sincos(imu_pitch, &s_pitch, &c_pitch);
+        ::sincos(imu_roll, &s_roll, &c_roll);
+        const V3 CoM{base2CoM * s_pitch, -base2CoM * s_roll, base2CoM * c_pitch * c_roll};
         const V3 accel{accel_x, accel_y, 0.0};
         const V3 H_G{Ixx * ang_vel.x, Iyy * ang_vel.y, Izz * ang_vel.z};
         const V3 H_Gdot = (H_G - last_HG) / dt;
