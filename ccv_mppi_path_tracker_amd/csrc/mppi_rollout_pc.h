@@ -384,13 +384,18 @@ __device__ __forceinline__ void pc_noise_ahead(const RolloutArgs& A, float (*slo
 // (worth it from kPartialMin steps on: a block of one or two steps is quicker step by step than as a batch of eight -- C2's
 //  H - 1 = 49 leaves one step, and batching it cost the four-wave kernel 1.6 us)
 constexpr int kPartialMin = 4;
-template <int MODEL, int MODE, class SH, bool ZLDS = false, bool FASTCLAMP = false, bool WIDE = false, bool PARTIAL = false>
+// NCTL > 0 (with PARTIAL): the number of control steps is known at compile time -- every mask folds, and what the masked steps
+// would have computed falls away as dead code (the reference's default horizon H = 15 leaves a last block of six: a quarter of
+// the batch).  The steps that remain are computed as before, bit for bit.
+template <int MODEL, int MODE, class SH, bool ZLDS = false, bool FASTCLAMP = false, bool WIDE = false, bool PARTIAL = false,
+          int NCTL = 0>
 __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh, PcState<MODEL>& S, double& cost,
                                                    const int b, const int lane, const int k, const int kk, const bool live,
                                                    const uint32_t kg,
                                                    const float (*ahead)[kPcSamples] = nullptr,   // pc_noise_ahead's slot
                                                    const int nctl_in = kTU) {
-    const int nctl = PARTIAL ? nctl_in : kTU;   // steps of this block that carry controls (wave-uniform)
+    static_assert(NCTL == 0 || (PARTIAL && NCTL < kTU), "a compile-time step count is a partial block's");
+    const int nctl = NCTL > 0 ? NCTL : (PARTIAL ? nctl_in : kTU);   // steps of this block that carry controls (wave-uniform)
     constexpr int UD = udim_of(MODEL);
     constexpr bool FB = MODEL == CCV_MPPI_FULL_BODY;
     constexpr bool COST = MODE != MODE_ROLLOUT;
@@ -503,8 +508,10 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
             s_ = s2;
             c_ = c2;
         }
-        S.sn = s_;
-        S.cs = c_;
+        if constexpr (NCTL == 0) {
+            S.sn = s_;
+            S.cs = c_;
+        }
     } else if constexpr (FB) {
         // full body needs sin / cos of four angles per step: heading = yaw + direction, direction, roll, pitch.  Every one
         // of them either is small (|direction| <= pi/4: a clamped control) or changes by a small step (yaw, roll, pitch:
@@ -615,13 +622,15 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
                     cost += in ? cz : 0.0;
                     cost += in ? cr : 0.0;
                 }
-                S.p_sdir = fb_sd[tt];
-                S.p_cdir = fb_cd[tt];
-                S.p_c2 = -A.fb_L * fb_sr[tt];                 // CoM.y (fb:482)
-                S.p_c3 = A.fb_L * fb_cp[tt] * fb_cr[tt];      // CoM.z
-                S.p_ac = u[tt][0] * u[tt][1];       // fb:471
-                S.p_v = u[tt][0];
-                S.p_rv = u[tt][3];
+                if (NCTL == 0 || tt < NCTL) {   // (a compile-time count: nothing reads the state past the last control step)
+                    S.p_sdir = fb_sd[tt];
+                    S.p_cdir = fb_cd[tt];
+                    S.p_c2 = -A.fb_L * fb_sr[tt];                 // CoM.y (fb:482)
+                    S.p_c3 = A.fb_L * fb_cp[tt] * fb_cr[tt];      // CoM.z
+                    S.p_ac = u[tt][0] * u[tt][1];       // fb:471
+                    S.p_v = u[tt][0];
+                    S.p_rv = u[tt][3];
+                }
             }
         }
     }
@@ -632,12 +641,14 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
     for (int tt = 0; tt < kTU; ++tt) {
         xv[tt] = x;
         yv[tt] = y;
-        if constexpr (SH::kStage) {
-            sh.p[b & (SH::kPBuf - 1)][tt][0][lane] = x;
-            sh.p[b & (SH::kPBuf - 1)][tt][1][lane] = y;
-        } else {
-            sh.p[b & (SH::kPBuf - 1)][tt][0][lane] = x - A.x0[0];
-            sh.p[b & (SH::kPBuf - 1)][tt][1][lane] = y - A.x0[1];
+        if (NCTL == 0 || tt <= NCTL) {   // (a compile-time count: the states past t = H - 1 are nobody's)
+            if constexpr (SH::kStage) {
+                sh.p[b & (SH::kPBuf - 1)][tt][0][lane] = x;
+                sh.p[b & (SH::kPBuf - 1)][tt][1][lane] = y;
+            } else {
+                sh.p[b & (SH::kPBuf - 1)][tt][0][lane] = x - A.x0[0];
+                sh.p[b & (SH::kPBuf - 1)][tt][1][lane] = y - A.x0[1];
+            }
         }
         if constexpr (FB) {
             // (the full-body kernels keep the reference's form: the one-wave kernel sits at 256 registers, and every
@@ -662,6 +673,7 @@ __device__ __forceinline__ bool pc_produce_batched(const RolloutArgs& A, SH& sh,
             }
         }
     }
+    if constexpr (NCTL > 0) return true;   // (the horizon's last block: the state is not carried any further)
     S.x = x;
     S.y = y;
     S.yaw = yawv[kTU];
