@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kR4Waves * 64, MODEL == CCV_MPPI_FULL_BODY ? 1 : 4)
     } else if (wv == 2) {
         // ---------------- distance wave: the states of block b as soon as the dynamics wave has published it
         // (round 3 tried handing every second one of the last blocks to the noise wave, which is idle from two thirds of the
-        //  kernel on: +1.5 us -- the loop is paced by the stores, 83 MB at the 5.1 TB/s this chip writes, not by this wave)
+        //  kernel on: +1.5 us -- the loop is priced by the instructions all four waves of a SIMD issue, not by this wave's share)
         int prune_on = 1;
         const int lane = r4_lane(A).lane;
         double cost = 0.0;
