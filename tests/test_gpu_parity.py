@@ -235,7 +235,8 @@ def test_kernel_variants_agree(monkeypatch, name):
 
 @pytest.mark.parametrize("wl,K,H", [("C2", 256, 50), ("C2", 1000, 50), ("C2", 130, 9), ("C2", 64, 3), ("C2", 4097, 128),
                                     ("C2", 777, 17), ("C2", 640, 25), ("C3", 1000, 50), ("C3", 321, 9), ("C3", 64, 3),
-                                    ("C3", 2049, 128)])
+                                    ("C3", 2049, 128), ("C2", 1000, 15), ("C3", 1000, 15)])   # (H = 15: the reference's default --
+                                    # a last block of six steps, the four-wave kernel's compile-time instantiation of the masked batch)
 def test_multi_wave_kernels_agree(monkeypatch, wl, K, H):
     """Diff-drive and steering run the four-wave kernel (noise / dynamics / distance / store wave, mppi_rollout_r4.h) by
     default; the three-wave kernel (mppi_rollout_r3.h) splits the same arithmetic over the same cost parts and must give
