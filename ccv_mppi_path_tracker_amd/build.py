@@ -20,7 +20,6 @@ HEADERS = ["mppi_kernels.h", "mppi_update.h", "mppi_launch.h", "mppi_rollout_pc.
            os.path.join("..", "..", "include", "ccv_mppi.h"), os.path.join("..", "..", "include", "ccv_mppi_host.h"),
            os.path.join("..", "..", "include", "ccv_mppi_node.hpp")]
 DEPS = SOURCES + HEADERS
-OBJDIR = os.path.join(_PKG, "lib", "obj")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -58,27 +57,41 @@ def _run(cmd, verbose):
 
 def build(force=False, verbose=False, extra_flags=(), out=None, jobs=None):
     """Compile every HIP source for gfx950 into LIB (or `out` for experiment builds); returns the path.  The translation
-    units are compiled in parallel (`jobs` at a time, default: the CPUs this process may use, at most 8) and linked."""
+    units are compiled in parallel (`jobs` at a time, default: the CPUs this process may use, at most 8) and linked.
+    Several processes may call this at once (the ranks of a launch that finds the library stale): one builds, under a file
+    lock and into a directory of its own, the others wait and take what it made."""
     if out is None and not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     target = out or LIB
-    objdir = OBJDIR if out is None else os.path.join(os.path.dirname(os.path.abspath(out)), "obj_" + os.path.basename(out))
-    os.makedirs(objdir, exist_ok=True)
-    cc = hipcc()
-    objs = [os.path.join(objdir, os.path.basename(s).rsplit(".", 1)[0] + ".o") for s in SOURCES]
-    cmds = [[cc] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", o, os.path.join(CSRC, s)] for s, o in zip(SOURCES, objs)]
-    if jobs is None:
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            jobs = len(os.sched_getaffinity(0))
-        except AttributeError:
-            jobs = os.cpu_count() or 1
-        jobs = max(1, min(8, jobs))
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(jobs) as pool:
-        list(pool.map(lambda c: _run(c, verbose), cmds))
-    _run([cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", target] + objs, verbose)
-    shutil.rmtree(objdir, ignore_errors=True)   # (every build compiles everything: the objects are of no further use)
+            if out is None and not force and not stale():   # (another process built it while this one waited)
+                return LIB
+            objdir = os.path.join(os.path.dirname(os.path.abspath(target)), "obj_%s_%d" % (os.path.basename(target), os.getpid()))
+            os.makedirs(objdir, exist_ok=True)
+            cc = hipcc()
+            objs = [os.path.join(objdir, os.path.basename(s).rsplit(".", 1)[0] + ".o") for s in SOURCES]
+            cmds = [[cc] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", o, os.path.join(CSRC, s)] for s, o in zip(SOURCES, objs)]
+            if jobs is None:
+                try:
+                    jobs = len(os.sched_getaffinity(0))
+                except AttributeError:
+                    jobs = os.cpu_count() or 1
+                jobs = max(1, min(8, jobs))
+            from concurrent.futures import ThreadPoolExecutor
+            try:
+                with ThreadPoolExecutor(jobs) as pool:
+                    list(pool.map(lambda c: _run(c, verbose), cmds))
+                tmp = target + ".tmp%d" % os.getpid()
+                _run([cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs, verbose)
+                os.replace(tmp, target)   # (atomic: a process that has the old library open keeps it)
+            finally:
+                shutil.rmtree(objdir, ignore_errors=True)   # (every build compiles everything: the objects are of no further use)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return target
 
 
