@@ -39,6 +39,25 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert b"gfx950" in capi.load().ccv_mppi_version()
 
 
+def test_two_processes_that_find_the_library_stale_do_not_race():
+    """The ranks of a multi-GPU launch import the package at the same moment; if the library is older than a source, each of
+    them used to compile into the same object directory and remove it when done (one rank's link then failed).  Now one builds
+    under a file lock and the others wait for it: both calls succeed and the library is fresh afterwards."""
+    lib = build.build()
+    old = os.path.getmtime(lib) - 10 * 365 * 86400.0
+    os.utime(lib, (old, old))                       # stale: older than every source
+    assert build.stale()
+    code = "from ccv_mppi_path_tracker_amd import build; print(build.build())"
+    procs = [subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+        assert out.strip().endswith("libccv_mppi_hip.so")
+    assert not build.stale()
+    assert not [d for d in os.listdir(build.LIBDIR) if d.startswith("obj_")]   # nobody's object directory is left behind
+
+
 def test_struct_layout_matches_c(tmp_path):
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ccv_mppi.h"\n'
