@@ -746,7 +746,7 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     }
     // wave priorities (pc_rotate_priority): measured -4 us on the three-wave kernel (C2), -3 % on the two-wave one (C4), and
     // with four levels -5 us on the four-wave kernel (43.4 -> 38.3 us at C2)
-    h->prio_rotate = h->coop == 3 ? 5 : h->coop ? 1 : 0;
+    h->prio_rotate = h->coop == 3 ? 2 : h->coop ? 1 : 0;   // (four-wave kernel: r4_rotate_priority's schedule 2, see there)
     if (const char* pv = std::getenv("CCV_MPPI_PRIO")) {
         const int v = std::atoi(pv);
         h->prio_rotate = v == 0 ? 0 : (v >= 2 && v <= 5 && h->coop == 3) ? v : h->prio_rotate;   // (2 .. 5: r4_rotate_priority's schedules)

@@ -156,10 +156,13 @@ __device__ __forceinline__ void pc_rotate_priority(const RolloutArgs& A, const i
     }
 }
 
-// four-wave kernel: the level from the workgroup's dispatch rank, the time block and the wave's role.  prio_rotate 5 (the
-// default): (role - rank - b) mod 4; 2: (rank + b + role) mod 4, round 2's schedule; 3, 4: the other two sign combinations
-// (CCV_MPPI_PRIO=2..5; measured kernel times at C2 on one box, with the prologue's rank priorities: 5: 32.2 us, 2: 32.5,
-// 4: about 2's, 3: +1.0)
+// four-wave kernel: the level from the workgroup's dispatch rank, the time block and the wave's role.  prio_rotate 2 (the
+// default): (rank + role + b) mod 4; 5: (role - rank - b) mod 4; 3, 4: the other two sign combinations (CCV_MPPI_PRIO=2..5).
+// Which of 2 and 5 is ahead depends on the kernel around them: with the prologue's rank priorities first in, 5 led by 0.3 us
+// (C2 32.2 against 32.5 us, round 3, gpurun_out/r3j); after the instruction diet of the dynamics and distance waves 2 leads --
+// five alternating pairs on one box (gpurun_out/r3bk): C2 31.47 against 32.02 us, C3 40.52 against 41.17 (42.7 against
+// 44.4 us per iteration), resident tick's kernel 36.1 against 37.4, wide turns 35.1 against 36.1; 4 and 3: +2 us, +1 us;
+// none: +4.6.  No difference where every wave is alone on its SIMD (the reference's default sizes).
 __device__ __forceinline__ void r4_rotate_priority(const RolloutArgs& A, const int b, const int role) {
     if (!A.prio_rotate) return;
     const int rank = (int)blockIdx.x / A.cu_count;
