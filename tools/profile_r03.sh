@@ -19,7 +19,9 @@ for w in C3 C4 fb_default dd_default; do python3 $R/bench.py --workload $w --ste
 echo "bench lines done"
 for w in C2 C3 C4 fb_default; do
   st=200; [ $w = C4 ] && st=100
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_$w -- python3 $R/bench.py --workload $w --steps $st --warmup 20 $Q > $O/${w}_bench_under_rocprof.json 2> $O/ktrace_$w.err
+  # (--no-closed-loop-leg: the resident loop launches the same kernel on another workload -- pose and window from the frame in HBM,
+  #  full windows only -- and has a kernel trace of its own below; with it in, 4 % of the launches averaged here ran 6 us longer)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_$w -- python3 $R/bench.py --workload $w --steps $st --warmup 20 $Q --no-closed-loop-leg > $O/${w}_bench_under_rocprof.json 2> $O/ktrace_$w.err
   find $O/ktrace_$w -name "*kernel_stats.csv" -exec cp {} $O/${w}_kernel_stats.csv \;
   echo "ktrace $w done"
 done
