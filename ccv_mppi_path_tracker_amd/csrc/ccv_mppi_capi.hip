@@ -746,10 +746,15 @@ int ccv_mppi_create(const ccv_mppi_config* cfg, ccv_mppi_handle** out) {
     }
     // wave priorities (pc_rotate_priority): measured -4 us on the three-wave kernel (C2), -3 % on the two-wave one (C4), and
     // with four levels -5 us on the four-wave kernel (43.4 -> 38.3 us at C2)
-    h->prio_rotate = h->coop == 3 ? 2 : h->coop ? 1 : 0;   // (four-wave kernel: r4_rotate_priority's schedule 2, see there)
-    if (const char* pv = std::getenv("CCV_MPPI_PRIO")) {
+    // four-wave kernel: (rank + level[role] + b) mod 4 with the roles' levels per model -- noise / dynamics / distance / store
+    // (r4_rotate_priority, mppi_rollout_pc.h: where the numbers are)
+    auto levels = [](int noise, int dynamics, int distance, int store) { return 16 + (noise | dynamics << 2 | distance << 4 | store << 6); };
+    const int kR4PrioLevels = h->cfg.model == CCV_MPPI_DIFF_DRIVE ? levels(3, 2, 1, 0)
+                              : h->cfg.model == CCV_MPPI_STEERING_DIFF_DRIVE ? levels(2, 3, 1, 0) : levels(0, 1, 2, 3);
+    h->prio_rotate = h->coop == 3 ? kR4PrioLevels : h->coop ? 1 : 0;
+    if (const char* pv = std::getenv("CCV_MPPI_PRIO")) {   // 0: off; 2 .. 5: the formula schedules; 16 + digits: a level table
         const int v = std::atoi(pv);
-        h->prio_rotate = v == 0 ? 0 : (v >= 2 && v <= 5 && h->coop == 3) ? v : h->prio_rotate;   // (2 .. 5: r4_rotate_priority's schedules)
+        h->prio_rotate = v == 0 ? 0 : (((v >= 2 && v <= 5) || (v >= 16 && v < 16 + 256)) && h->coop == 3) ? v : h->prio_rotate;
     }
 
     // Exact window pruning in the distance loop (pc_prune_window).  Measured on one box, kernel us off -> on: diff drive

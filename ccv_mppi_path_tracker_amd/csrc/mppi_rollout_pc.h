@@ -156,16 +156,23 @@ __device__ __forceinline__ void pc_rotate_priority(const RolloutArgs& A, const i
     }
 }
 
-// four-wave kernel: the level from the workgroup's dispatch rank, the time block and the wave's role.  prio_rotate 2 (the
-// default): (rank + role + b) mod 4; 5: (role - rank - b) mod 4; 3, 4: the other two sign combinations (CCV_MPPI_PRIO=2..5).
-// Which of 2 and 5 is ahead depends on the kernel around them: with the prologue's rank priorities first in, 5 led by 0.3 us
-// (C2 32.2 against 32.5 us, round 3, gpurun_out/r3j); after the instruction diet of the dynamics and distance waves 2 leads --
-// five alternating pairs on one box (gpurun_out/r3bk): C2 31.47 against 32.02 us, C3 40.52 against 41.17 (42.7 against
-// 44.4 us per iteration), resident tick's kernel 36.1 against 37.4, wide turns 35.1 against 36.1; 4 and 3: +2 us, +1 us;
-// none: +4.6.  No difference where every wave is alone on its SIMD (the reference's default sizes).
+// four-wave kernel: the level from the workgroup's dispatch rank, the time block and the wave's role.
+//   prio_rotate >= 16: (rank + level[role] + b) mod 4 with level[] = the four base-4 digits of prio_rotate - 16 (digit 0: noise
+//   wave, 1: dynamics, 2: distance, 3: store) -- the default, with one table per model (ccv_mppi_capi.hip: kR4PrioLevels);
+//   2: level[role] = role, i.e. (rank + role + b); 5: (role - rank - b); 3, 4: the other two sign combinations (CCV_MPPI_PRIO).
+// What matters, measured at C2 on one box (gpurun_out/r3bn, r3bj): no priorities 36.6 us; the prologue's rank priorities only
+// 35.3; rank only, constant 34.5; (rank + role) 34.5; (rank + b) 32.4; (rank + role + b) 31.7; (rank + role - b) 32.9 -- the
+// rotation with the time block is worth 3 us, its direction 1, the role term 0.7.  And WHICH role sits on which level another
+// 0.7 us at C2 and 2 us at C3 (all 24 assignments, gpurun_out/r3br): diff drive noise 3 / dynamics 2 / distance 1 / store 0
+// 31.9 us against 32.6 for 0 / 1 / 2 / 3, steering 2 / 3 / 1 / 0 39.7 against 41.7 (and 42.1 with diff drive's) -- the roles'
+// blocks differ in length between the models, and the best interleaving with them.
 __device__ __forceinline__ void r4_rotate_priority(const RolloutArgs& A, const int b, const int role) {
     if (!A.prio_rotate) return;
     const int rank = (int)blockIdx.x / A.cu_count;
+    if (A.prio_rotate >= 16) {
+        pc_set_priority((rank + (((A.prio_rotate - 16) >> (2 * role)) & 3) + b) & 3);
+        return;
+    }
     switch (A.prio_rotate) {
         case 2: pc_set_priority((rank + role + b) & 3); break;
         case 3: pc_set_priority((rank + role - b) & 3); break;
