@@ -56,7 +56,14 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
     S.p_cdir = 1.0;
     fast_sincos(A.x0[2], S.sn, S.cs);
     __syncthreads();   // (one wave: the staged window and warm start are visible to all its lanes)
+    // Wave priorities: two (or more) of these waves share a SIMD and run the same code in step; left alone they contend for
+    // the same pipe at the same time.  Level (-rank - b) mod 4 -- the workgroup's dispatch rank on its CU, rotating with the
+    // time block -- lets one run ahead for a block, then the other: C4 203.3 -> 191.1 us on one box (gpurun_out/r3by; the
+    // other rotations tried there: (rank - b) 192.2, (rank - b / 2) 191.8, (rank + b) 194.0, two levels instead of four 195,
+    // a constant level per wave: no gain, levels by phase (noise + dynamics high / distance low): +7 us).  CCV_MPPI_PRIO=0: off.
+    const int prio_rank = A.prio_rotate ? (int)blockIdx.x / A.cu_count : 0;
     for (int b = 0; b < nblocks; ++b) {
+        if (A.prio_rotate) pc_set_priority((-prio_rank - b) & 3);
         // ---------------- states and controls of steps 8b .. 8b+7
         bool done = false;
         const int nctl = min(kTU, H - 1 - b * kTU);   // steps of this block that carry controls
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(kPcSamples, 2) void k_rollout_solo(const RolloutArg
             default: break;
         }
     }
+    if (A.prio_rotate) __builtin_amdgcn_s_setprio(0);
     // ---------------- weights and this wave's share of the update (dd:216-237)
     using Rows = UpdRowsT<kTU * udim_of(MODEL), 1>;
     const int R = (H - 1) * udim_of(MODEL);
